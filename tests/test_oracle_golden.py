@@ -1,0 +1,105 @@
+"""Pins oracle/stm_oracle.py (the CPU restatement) to the golden vectors that
+oracle/make_golden.py produced by running the UNMODIFIED reference.
+The reference ships no tests of its own for this path, so these fixtures are the pin."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stm_oracle as O
+from oracle import weights as Wt
+
+torch.set_grad_enabled(False)
+TOL = 2e-6   # same ops, same library: expected bit-exact on this image; slack for other CPUs
+
+
+@pytest.fixture(scope="module")
+def ops(golden_dir):
+    with np.load(os.path.join(golden_dir, "ops_small.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
+    assert len(keys["prop"]) == 597 and len(keys["fuse"]) == 12
+    assert {k: list(v) for k, v in Wt.prop_spec().items()} == keys["prop"]
+    assert {k: list(v) for k, v in Wt.fuse_spec().items()} == keys["fuse"]
+
+
+def test_synthetic_weights_are_reproducible(ops, synthetic_states):
+    sd, fsd = synthetic_states
+    assert Wt.state_fingerprint(sd) == pytest.approx(float(ops["fingerprint_prop"]), rel=1e-12)
+    assert Wt.state_fingerprint(fsd) == pytest.approx(float(ops["fingerprint_fuse"]), rel=1e-12)
+
+
+def test_memory_read(ops):
+    out = O.memory_read(T(ops["mr_mk"]), T(ops["mr_mv"]), T(ops["mr_qk"]), 20)
+    assert float((out - T(ops["mr_out"])).abs().max()) <= TOL
+
+
+def test_memory_read_topk_larger_than_memory_raises(ops):
+    # reference behaviour: torch.topk raises when THW < top_k (SURVEY.md §7 hard part 2)
+    with pytest.raises(RuntimeError):
+        O.memory_read(T(ops["mr_mk"])[:, :, :1, :2, :2], T(ops["mr_mv"])[:, :, :1, :2, :2], T(ops["mr_qk"])[:, :, :2, :2], 20)
+
+
+def test_aggregate(ops):
+    p = T(ops["ag_in"])
+    assert float((O.aggregate_wbg(p, True) - T(ops["ag_soft"])).abs().max()) <= TOL
+    assert float((O.aggregate_wbg(p, True, hard=True) - T(ops["ag_hard"])).abs().max()) <= TOL
+    assert float((O.aggregate_sbg(p, True) - T(ops["ag_sbg"])).abs().max()) <= TOL
+    assert float((O.aggregate_wbg(p, False) - T(ops["ag_soft"])[1:]).abs().max()) <= TOL
+
+
+def test_get_attention(ops):
+    a = O.get_attention(T(ops["at_mk"]), T(ops["at_pos"]), T(ops["at_neg"]), T(ops["at_qk"]))
+    assert float((a - T(ops["at_out"])).abs().max()) <= TOL
+
+
+def test_fusion_net(ops, synthetic_states):
+    o = O.fusion_net(synthetic_states[1], T(ops["fu_im"]), T(ops["fu_s1"]), T(ops["fu_s2"]), T(ops["fu_at"]), T(ops["fu_tm"]))
+    assert float((o - T(ops["fu_out"])).abs().max()) <= 1e-5
+
+
+def test_encoders_and_decoder(ops, synthetic_states):
+    sd = synthetic_states[0]
+    k, v = O.memorize(sd, T(ops["en_frame"]), T(ops["en_masks"]))
+    assert float((k - T(ops["en_mk"])).abs().max()) <= 1e-5
+    assert float((v - T(ops["en_mv"])).abs().max()) <= 1e-5
+    q = O.get_query_values(sd, T(ops["en_frame"]))
+    for got, name in zip(q, ("en_f16", "en_f8", "en_f4", "en_qk", "en_qv")):
+        assert float((got - T(ops[name])).abs().max()) <= 1e-5, name
+    d = O.decoder(sd, T(ops["de_m4"]), q[1], q[2])
+    assert float((d - T(ops["de_out"])).abs().max()) <= 1e-4
+
+
+def test_pad_divide_by():
+    x = torch.ones(1, 3, 480, 854)
+    y, pad = O.pad_divide_by(x, 16)
+    assert y.shape[-2:] == (480, 864) and pad == (5, 5, 0, 0)
+    y, pad = O.pad_divide_by(torch.ones(1, 1, 120, 150), 16)
+    assert y.shape[-2:] == (128, 160) and pad == (5, 5, 4, 4)
+    y, pad = O.pad_divide_by(torch.ones(1, 1, 101, 35), 16)     # odd deltas: low side gets floor
+    assert pad == (6, 7, 5, 6)
+
+
+def test_end_to_end_inference_core(golden_dir, synthetic_states):
+    """Three interactions (incl. fusion between interacted frames) vs the reference's
+    InferenceCore: identical masks, probabilities and schedule trace."""
+    sd, fsd = synthetic_states
+    with np.load(os.path.join(golden_dir, "e2e_small.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    c = json.loads(str(g["config"]))
+    images, gt = O.synthetic_clip(c["t"], c["h"], c["w"], c["k"], c["seed"])
+    core = O.OracleCore(sd, fsd, images, c["k"], mem_freq=c["mem_freq"], top_k=c["top_k"])
+    for n, idx in enumerate(c["interactions"]):
+        out = core.interact(gt[idx], idx)
+        assert (out != g[f"masks_{n}"]).mean() <= 1e-4
+        assert float((core.prob - T(g[f"prob_{n}"])).abs().max()) <= 1e-4
+    assert " ".join(core.trace) == str(g["trace"])
