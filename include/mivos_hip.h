@@ -1,0 +1,166 @@
+/*
+ * mivos_hip.h — C ABI of libmivos_hip.so, the MI355X (gfx950 / CDNA4) compute library under the
+ * MiVOS propagation + difference-aware-fusion drop-in (package mivos_amd).
+ *
+ * The reference (hkchengrex/MiVOS) has NO native/FFI layer on this path: every FLOP runs inside
+ * stock PyTorch ops called from Python classes.  Each entry point below therefore cites the
+ * reference *Python* code it replaces (paths relative to the reference root) — that is the
+ * interface a maintainer would bind instead of the torch ops (see INTEGRATION.md for the ctypes
+ * stub).  Conventions:
+ *   - every function returns 0 on success, a negative mivos_status on failure; the message of the
+ *     last failure on the calling thread is available from mivos_last_error();
+ *   - all pointers are DEVICE pointers owned by the caller (PyTorch tensors in the Python host);
+ *     nothing is allocated or freed inside the library; workspaces are passed in explicitly;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous;
+ *   - activations are fp32 "NHWC": element (n, y, x, c) lives at
+ *         base + n*nstride + (y*W + x)*pstride + c        (strides in ELEMENTS)
+ *     so channel slices / concatenations / memory-bank slots are expressed with strides, not copies;
+ *   - single-channel maps (masks, probabilities, logits) are planar [planes][H*W].
+ * Re-entrancy: functions keep no global state besides the thread-local error string.
+ */
+#ifndef MIVOS_HIP_H_
+#define MIVOS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIVOS_ABI_VERSION 1
+
+typedef enum {
+  MIVOS_OK = 0,
+  MIVOS_ERR_INVALID_ARGUMENT = -1, /* bad shape / alignment / unsupported configuration      */
+  MIVOS_ERR_LAUNCH = -2,           /* hipLaunch / runtime error (message has hipGetErrorString) */
+  MIVOS_ERR_DEVICE = -3,           /* not a gfx950 device                                     */
+  MIVOS_ERR_TOPK_RANGE = -4        /* top_k larger than the memory (reference: torch.topk raises
+                                      "selected index k out of range", prop_net.py:54)           */
+} mivos_status;
+
+int mivos_version(void);
+const char *mivos_last_error(void);
+/* 0 iff `device` is a gfx950 (MI355X) GPU. */
+int mivos_device_check(int device);
+
+/* --------------------------------------------------------------------------------------------
+ * Fused convolution (implicit GEMM on fp32 MFMA, exact-f32 accumulate).
+ * Replaces nn.Conv2d (+ eval BatchNorm2d folded into scale/bias, + ReLU, + residual add) in
+ *   model/propagation/mod_resnet.py:92-112 (Bottleneck), torchvision resnet50 (modules.py:70),
+ *   modules.py:28-35 (ResBlock), :100-104 (UpsampleBlock), :113-114 (KeyValue),
+ *   prop_net.py:23-31 (Decoder), model/fusion_net.py:32-50 (FusionNet).
+ *   y = act_out( conv(act_in(x), w) * scale + bias + res )
+ * w is OHWI: [Cout][KH][KW][Cin] (K = KH*KW*Cin contiguous).  Cin must be a power of two >= 4
+ * (pad the channel dimension with zero weights otherwise).  Output channels [0, split) go to y,
+ * channels [split, Cout) go to y2 (split == Cout or y2 == NULL: single destination) — this is how
+ * KeyValue's two projections run as one GEMM and land in two memory-bank tensors.
+ * -------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *x;     /* input,  N x H x W x Cin  (strided NHWC)                                 */
+  const float *w;     /* weights, OHWI                                                            */
+  const float *scale; /* per-Cout multiplier (folded BN gamma/sqrt(var+eps)) or NULL = 1          */
+  const float *bias;  /* per-Cout additive term or NULL = 0                                       */
+  const float *res;   /* residual, N x Ho x Wo x Cout (strided NHWC) or NULL                       */
+  float *y;           /* output channels [0, split)                                               */
+  float *y2;          /* output channels [split, Cout) or NULL                                    */
+  int32_t N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+  int32_t split;      /* see above; set to Cout when y2 is NULL                                   */
+  int32_t relu_in;    /* apply max(0,.) to x while loading (pre-activation ResBlock)              */
+  int32_t relu_out;   /* apply max(0,.) before the store                                          */
+  int64_t x_nstride, x_pstride;
+  int64_t y_nstride, y_pstride;
+  int64_t y2_nstride, y2_pstride;
+  int64_t res_nstride, res_pstride; /* res_nstride == 0 broadcasts one residual over the batch   */
+} mivos_conv_desc;
+
+int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream);
+
+/* MaxPool2d(3, stride 2, pad 1) on NHWC (mod_resnet.py:121 / torchvision stem). C % 4 == 0. */
+int mivos_maxpool3x3s2(const float *x, float *y, int N, int H, int W, int C, void *stream);
+
+/* x = skip + bilinear_up2(up), align_corners=False (modules.py:102).  skip is broadcast over the
+ * batch when skip_nstride == 0.  up: N x h x w x C, skip/out: N x 2h x 2w x C, all dense NHWC. */
+int mivos_upsample2x_add(const float *skip, int64_t skip_nstride, const float *up, float *out,
+                         int N, int h, int w, int C, void *stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Space-time memory read: affinity (MFMA) -> streaming per-query top-k -> softmax over the k
+ * survivors -> sparse value readout.  Replaces EvalMemoryReader.forward + softmax_w_g_top
+ * (prop_net.py:47-63, 81-108) without materialising the [THW x HW] affinity.
+ *   keys   [n_obj][n_mem][CK=128]  (n_mem = T*H*W memory positions, row = one position)
+ *   values [n_obj][n_mem][CV=512]
+ *   qk     [n_q][128]              (shared by all objects, NOT pre-scaled; the kernel applies
+ *                                   1/sqrt(128) exactly like prop_net.py:86)
+ *   out    [n_obj][n_q] rows of 512 floats at out + o*out_ostride + q*out_pstride
+ * workspace: mivos_memory_read_workspace_bytes() bytes of device scratch.
+ * Returns MIVOS_ERR_TOPK_RANGE when top_k > n_mem (reference raises).  top_k <= 64.
+ * -------------------------------------------------------------------------------------------- */
+int64_t mivos_memory_read_workspace_bytes(int n_obj, int64_t n_mem, int n_q, int top_k);
+int mivos_memory_read_topk(const float *keys, int64_t keys_ostride, const float *values,
+                           int64_t values_ostride, const float *qk, float *out, int64_t out_ostride,
+                           int64_t out_pstride, int n_obj, int64_t n_mem, int n_q, int top_k,
+                           void *workspace, int64_t workspace_bytes, void *stream);
+/* Debug/test export: same selection, but writes the k selected memory indices (ascending score
+ * rank, best first) and their normalised softmax weights instead of the readout. */
+int mivos_memory_read_topk_indices(const float *keys, int64_t keys_ostride, const float *qk,
+                                   int32_t *idx_out, float *weight_out, int n_obj, int64_t n_mem,
+                                   int n_q, int top_k, void *workspace, int64_t workspace_bytes,
+                                   void *stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Difference-aware attention alignment: W = softmax_m(mk^T qk / sqrt(128)) (T = 1, all positions),
+ * out[0][q] = sum_m pos16[m] W[m,q], out[1][q] = sum_m neg16[m] W[m,q]; W never materialised.
+ * Replaces AttentionMemory.forward + the two [1 x HW] @ [HW x HW] products in
+ * PropagationNetwork.get_attention (prop_net.py:115-129, 187-196) and attn_network.py:12-28,65-79.
+ *   mk [n_obj][n_pos][128], qk [n_pos][128], pos16/neg16 [n_obj][n_pos], out [n_obj][2][n_pos]
+ * -------------------------------------------------------------------------------------------- */
+int mivos_attention_align(const float *mk, const float *qk, const float *pos16, const float *neg16,
+                          float *out, int n_obj, int n_pos, void *stream);
+
+/* ---- planar single-channel maps ------------------------------------------------------------- */
+
+/* F.interpolate(mode='area') to 1/16 resolution (prop_net.py:195-196): mean over 16x16 blocks. */
+int mivos_area_pool16(const float *x, float *y, int planes, int H, int W, void *stream);
+
+/* F.interpolate(mode='bilinear', align_corners=False) from h x w to H x W on `planes` maps
+ * (prop_net.py:30 x4, :198 x16); act = 0 none, 1 sigmoid (prop_net.py:181). */
+int mivos_resize_bilinear(const float *x, float *y, int planes, int h, int w, int H, int W, int act,
+                          void *stream);
+
+/* aggregate_wbg (model/aggregate.py:22-37): prob [K][P] -> out [K+1][P] (keep_bg=1) or [K][P]. */
+int mivos_aggregate_wbg(const float *prob, float *out, int K, int64_t P, int keep_bg, int hard,
+                        void *stream);
+/* aggregate_sbg (model/aggregate.py:4-20): background fixed at 0.5. */
+int mivos_aggregate_sbg(const float *prob, float *out, int K, int64_t P, int keep_bg, int hard,
+                        void *stream);
+
+/* torch.argmax(prob, dim=0) -> uint8 (inference_core.py:259-260, :280); first index wins ties.
+ * prob plane c at prob + c*plane_stride. */
+int mivos_argmax_u8(const float *prob, int64_t plane_stride, uint8_t *out, int planes, int64_t P,
+                    void *stream);
+
+/* pos = clamp(mask - prob, 0, 1), neg = clamp(prob - mask, 0, 1)  (inference_core.py:231-233). */
+int mivos_mask_diff(const float *mask, const float *prob, float *pos, float *neg, int64_t n,
+                    void *stream);
+
+/* y = 1/(1+exp(-x)) (inference_core.py:214). */
+int mivos_sigmoid(const float *x, float *y, int64_t n, void *stream);
+
+/* "others" masks of memorize (prop_net.py:150-157): others[i] = sum_{j != i} masks[j]. */
+int mivos_mask_others(const float *masks, float *others, int K, int64_t P, void *stream);
+
+/* Interleave up to 16 planar sources into dense NHWC [N][P][C] (torch.cat along channels of
+ * modules.py:54 and fusion_net.py:38, plus zero padding of the channel dimension).
+ * channel c of batch n reads plane[c] + n*nstride[c] (NULL plane: the constant cval[c]). */
+typedef struct {
+  const float *plane[16];
+  int64_t nstride[16];
+  float cval[16];
+  int32_t C;
+} mivos_interleave_desc;
+int mivos_interleave_planes(const mivos_interleave_desc *d, float *out, int N, int64_t P, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIVOS_HIP_H_ */

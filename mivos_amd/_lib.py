@@ -1,0 +1,81 @@
+"""ctypes binding of libmivos_hip.so (C ABI: include/mivos_hip.h).
+
+The product path has NO fallback: if the shared library is missing, cannot be loaded or the
+device is not a gfx950, every compute entry point raises.  (Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C mivos_amd/csrc``.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmivos_hip.so")
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class ConvDesc(C.Structure):
+    """mivos_conv_desc"""
+    _fields_ = [("x", vp), ("w", vp), ("scale", vp), ("bias", vp), ("res", vp), ("y", vp), ("y2", vp),
+                ("N", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("KH", i32), ("KW", i32),
+                ("stride", i32), ("pad", i32), ("Ho", i32), ("Wo", i32), ("split", i32),
+                ("relu_in", i32), ("relu_out", i32),
+                ("x_nstride", i64), ("x_pstride", i64), ("y_nstride", i64), ("y_pstride", i64),
+                ("y2_nstride", i64), ("y2_pstride", i64), ("res_nstride", i64), ("res_pstride", i64)]
+
+
+class InterleaveDesc(C.Structure):
+    """mivos_interleave_desc"""
+    _fields_ = [("plane", vp * 16), ("nstride", i64 * 16), ("cval", f32 * 16), ("C", i32)]
+
+
+# name -> (restype, argtypes); every symbol include/mivos_hip.h declares
+PROTOTYPES = {
+    "mivos_version": (C.c_int, []),
+    "mivos_last_error": (C.c_char_p, []),
+    "mivos_device_check": (C.c_int, [C.c_int]),
+    "mivos_conv2d_fused": (C.c_int, [C.POINTER(ConvDesc), vp]),
+    "mivos_maxpool3x3s2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_upsample2x_add": (C.c_int, [vp, i64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_memory_read_workspace_bytes": (i64, [C.c_int, i64, C.c_int, C.c_int]),
+    "mivos_memory_read_topk": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
+    "mivos_memory_read_topk_indices": (C.c_int, [vp, i64, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
+    "mivos_attention_align": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "mivos_area_pool16": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_resize_bilinear": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_aggregate_wbg": (C.c_int, [vp, vp, C.c_int, i64, C.c_int, C.c_int, vp]),
+    "mivos_aggregate_sbg": (C.c_int, [vp, vp, C.c_int, i64, C.c_int, C.c_int, vp]),
+    "mivos_argmax_u8": (C.c_int, [vp, i64, vp, C.c_int, i64, vp]),
+    "mivos_mask_diff": (C.c_int, [vp, vp, vp, vp, i64, vp]),
+    "mivos_sigmoid": (C.c_int, [vp, vp, i64, vp]),
+    "mivos_mask_others": (C.c_int, [vp, vp, C.c_int, i64, vp]),
+    "mivos_interleave_planes": (C.c_int, [C.POINTER(InterleaveDesc), vp, C.c_int, i64, vp]),
+}
+
+_lib = None
+
+
+class MivosHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library; raises if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise MivosHipError(f"{LIB_PATH} not found: the HIP library is the only compute path of mivos_amd "
+                                "(build it with __graft_entry__.build()); there is no CPU/PyTorch fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().mivos_last_error().decode(errors="replace")
+        if rc == -4:      # MIVOS_ERR_TOPK_RANGE: same exception type + wording as torch.topk in the reference
+            raise RuntimeError(msg)
+        raise MivosHipError(f"libmivos_hip error {rc}: {msg}")

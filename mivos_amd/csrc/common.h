@@ -1,0 +1,29 @@
+// Shared host/device helpers for libmivos_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mivos_hip.h"
+
+namespace mivos {
+
+// thread-local last error string (mivos_last_error)
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return MIVOS_OK;
+}
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 32x32 MFMA C/D layout (cdna guide §3): lane l, register r -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31
+__device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+}  // namespace mivos

@@ -1,0 +1,281 @@
+// Fused NHWC convolution as an implicit GEMM on the CDNA4 fp32 matrix cores.
+//
+//   C[M = N*Ho*Wo pixels][Cout] = A[M][K = KH*KW*Cin] x B[K][Cout],   B = OHWI weights (K contiguous)
+//
+// Why fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity budget of this path is |dlogit| <= 1e-3 and
+// bf16/fp16 operands miss it by 16-100x (SURVEY.md §7 hard part 1); the f32 MFMA is bit-for-bit an
+// fmaf chain at 157 TF/s peak, so it is the exact path every other variant is checked against.
+//
+// Tiling (wave64, 4 waves / workgroup): block tile BM x BN x 32, wave tile (BM/WGM) x (BN/WGN) made
+// of 32x32 MFMA tiles.  Both operands are staged through LDS with K contiguous and a 36-float row
+// pitch: a lane (i = lane&31, h = lane>>5) fetches its fragment with ONE ds_read_b128 at
+// row i, k = 8*kk + 4*h (conflict-free for the 16-lane b128 groups, MI355X_MICROARCH §LDS) and
+// feeds 4 MFMAs from it (the k-permutation is the same for A and B, so the product is unchanged).
+// Global->LDS goes through registers (float4 per lane, one 128-B line per 8 lanes) because conv
+// zero-padding needs per-element predication; tile k+1 is fetched while tile k is multiplied.
+// Epilogue (fused): * scale[c] + bias[c] (+ residual) (ReLU) and a two-destination channel split.
+#include "common.h"
+
+namespace mivos {
+
+struct ConvP {
+  const float *x, *w, *scale, *bias, *res;
+  float *y, *y2;
+  int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, split, relu_in, relu_out;
+  int log2Cin, M, Ktot, HoWo, tiles_n;
+  long long x_ns, x_ps, y_ns, y_ps, y2_ns, y2_ps, r_ns, r_ps;
+};
+
+constexpr int BK = 32;   // k-chunk (floats) per pipeline stage
+constexpr int LDK = 36;  // LDS row pitch in floats (32 + 4 pad)
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int MT = TM / 32, NT = TN / 32;
+  constexpr int A_LD = BM / 32, B_LD = BN / 32;  // float4 loads per thread and stage
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int STAGE = (BM + BN) * LDK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int bid = blockIdx.x;
+  const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
+
+  // ---- loader state: thread -> (row lrow + 32 j, float4 k4 of the 32-wide chunk)
+  const int k4 = tid & 7, lrow = tid >> 3;
+  const float *a_base[A_LD];
+  int a_ih0[A_LD], a_iw0[A_LD];
+  bool a_ok[A_LD];
+#pragma unroll
+  for (int j = 0; j < A_LD; ++j) {
+    int m = m0 + lrow + 32 * j;
+    a_ok[j] = m < p.M;
+    int mm = a_ok[j] ? m : 0;
+    int n = mm / p.HoWo, rem = mm - n * p.HoWo;
+    int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+    a_ih0[j] = oh * p.stride - p.pad;
+    a_iw0[j] = ow * p.stride - p.pad;
+    a_base[j] = p.x + (long long)n * p.x_ns;
+  }
+  const float *b_ptr[B_LD];
+  bool b_ok[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    int n = n0 + lrow + 32 * j;
+    b_ok[j] = n < p.Cout;
+    b_ptr[j] = p.w + (long long)(b_ok[j] ? n : 0) * p.Ktot;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  f32x4 ra[A_LD], rb[B_LD];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  auto gload = [&](int k0) {
+    const int k = k0 + 4 * k4;
+    const bool kok = k < p.Ktot;
+    const int tap = k >> p.log2Cin, c = k & (p.Cin - 1);
+    int kh, kw;
+    if (p.KW == 1) { kh = tap; kw = 0; }            // (KH == KW on this path)
+    else if (p.KW == 3) { kh = tap / 3; kw = tap - 3 * kh; }
+    else { kh = tap / p.KW; kw = tap - p.KW * kh; }
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+      const bool ok = a_ok[j] && kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      f32x4 v = zero4;
+      if (ok) v = *reinterpret_cast<const f32x4 *>(a_base[j] + ((long long)ih * p.W + iw) * p.x_ps + c);
+      if (p.relu_in) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      f32x4 v = zero4;
+      if (b_ok[j] && kok) v = *reinterpret_cast<const f32x4 *>(b_ptr[j] + k);
+      rb[j] = v;
+    }
+  };
+  auto lwrite = [&](int buf) {
+    float *A = lds + buf * STAGE, *B = A + BM * LDK;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4 *>(A + (lrow + 32 * j) * LDK + 4 * k4) = ra[j];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) *reinterpret_cast<f32x4 *>(B + (lrow + 32 * j) * LDK + 4 * k4) = rb[j];
+  };
+
+  const int nk = (p.Ktot + BK - 1) / BK;
+  gload(0);
+  lwrite(0);
+  __syncthreads();
+  const int frag_off = (lane & 31) * LDK + 4 * (lane >> 5);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const float *A = lds + (kt & 1) * STAGE + wm * TM * LDK + frag_off;
+    const float *B = lds + (kt & 1) * STAGE + (BM + wn * TN) * LDK + frag_off;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4 *>(A + i * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) b[i] = *reinterpret_cast<const f32x4 *>(B + i * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lwrite((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns channel (lane&31) of each n-tile, 16 pixel rows per (m-tile, n-tile)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * TN + j * 32 + (lane & 31);
+    if (n >= p.Cout) continue;
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float bi = p.bias ? p.bias[n] : 0.f;
+    float *dst;
+    long long d_ns, d_ps;
+    int dn;
+    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_ps = p.y_ps; dn = n; }
+    else { dst = p.y2; d_ns = p.y2_ns; d_ps = p.y2_ps; dn = n - p.split; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM + i * 32 + mfma32_row(r, lane);
+        if (m >= p.M) continue;
+        const int img = m / p.HoWo, pix = m - img * p.HoWo;
+        float v = acc[i][j][r] * sc + bi;
+        if (p.res) v += p.res[(long long)img * p.r_ns + (long long)pix * p.r_ps + n];
+        if (p.relu_out) v = fmaxf(v, 0.f);
+        dst[(long long)img * d_ns + (long long)pix * d_ps + dn] = v;
+      }
+    }
+  }
+}
+
+// ---- Cout == 1 (decoder.pred 256->1, FusionNet final 32->1): a GEMM would waste 31/32 of every MFMA.
+// LPP lanes share one output pixel, each lane reduces 32 input channels over the KHxKW taps, then a
+// butterfly over the LPP lanes.  Weights (<= 9*256 floats) live in LDS.
+template <int LPP>
+__global__ __launch_bounds__(256) void conv_cout1_kernel(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  for (int i = threadIdx.x; i < p.Ktot; i += 256) wl[i] = p.w[i];
+  __syncthreads();
+  const int sub = threadIdx.x % LPP;
+  const long long m = ((long long)blockIdx.x * 256 + threadIdx.x) / LPP;
+  const bool ok = m < p.M;
+  const int mm = ok ? (int)m : 0;
+  const int img = mm / p.HoWo, pix = mm - img * p.HoWo;
+  const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
+  const float *xb = p.x + (long long)img * p.x_ns;
+  float acc = 0.f;
+  const int c0 = sub * 32;
+  for (int kh = 0; kh < p.KH; ++kh) {
+    const int ih = oh * p.stride - p.pad + kh;
+    if ((unsigned)ih >= (unsigned)p.H) continue;
+    for (int kw = 0; kw < p.KW; ++kw) {
+      const int iw = ow * p.stride - p.pad + kw;
+      if ((unsigned)iw >= (unsigned)p.W) continue;
+      const f32x4 *px = reinterpret_cast<const f32x4 *>(xb + ((long long)ih * p.W + iw) * p.x_ps + c0);
+      const f32x4 *pw = reinterpret_cast<const f32x4 *>(wl + (kh * p.KW + kw) * p.Cin + c0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        f32x4 v = px[q], w4 = pw[q];
+        if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        acc = fmaf(v.x, w4.x, acc); acc = fmaf(v.y, w4.y, acc);
+        acc = fmaf(v.z, w4.z, acc); acc = fmaf(v.w, w4.w, acc);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = LPP / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (ok && sub == 0) {
+    float v = acc * (p.scale ? p.scale[0] : 1.f) + (p.bias ? p.bias[0] : 0.f);
+    if (p.res) v += p.res[(long long)img * p.r_ns + (long long)pix * p.r_ps];
+    if (p.relu_out) v = fmaxf(v, 0.f);
+    p.y[(long long)img * p.y_ns + (long long)pix * p.y_ps] = v;
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static int launch_igemm(ConvP &p, hipStream_t st) {
+  const int tiles_m = cdiv(p.M, BM);
+  p.tiles_n = cdiv(p.Cout, BN);
+  const size_t lds = 2ull * (BM + BN) * LDK * sizeof(float);
+  auto kern = conv_igemm_kernel<BM, BN, WGM, WGN>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(conv_igemm): %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(256), lds, st, p);
+  return check_launch("conv_igemm");
+}
+
+}  // namespace mivos
+
+using namespace mivos;
+
+extern "C" int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream) {
+  if (!d || !d->x || !d->w || !d->y) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: null pointer");
+  if (d->Cin < 4 || (d->Cin & (d->Cin - 1))) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: Cin=%d must be a power of two >= 4", d->Cin);
+  if (d->KH != d->KW || d->KH < 1 || d->stride < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: unsupported kernel %dx%d stride %d", d->KH, d->KW, d->stride);
+  if (d->Ho != (d->H + 2 * d->pad - d->KH) / d->stride + 1 || d->Wo != (d->W + 2 * d->pad - d->KW) / d->stride + 1)
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: Ho/Wo inconsistent with H/W/pad/stride");
+  if ((d->x_pstride & 3) || (d->x_nstride & 3) || ((uintptr_t)d->x & 15) || ((uintptr_t)d->w & 15))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: x / w must be 16-byte aligned with strides %% 4 == 0");
+  if (d->N < 1 || d->Cout < 1 || (long long)d->N * d->Ho * d->Wo > 0x7fffffffLL) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: bad N/Cout");
+  const bool dual = d->y2 != nullptr && d->split < d->Cout;
+  ConvP p;
+  p.x = d->x; p.w = d->w; p.scale = d->scale; p.bias = d->bias; p.res = d->res; p.y = d->y; p.y2 = d->y2;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+  p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.split = dual ? d->split : d->Cout;
+  p.relu_in = d->relu_in; p.relu_out = d->relu_out;
+  p.log2Cin = __builtin_ctz(d->Cin);
+  p.HoWo = d->Ho * d->Wo; p.M = d->N * p.HoWo; p.Ktot = d->KH * d->KW * d->Cin; p.tiles_n = 1;
+  p.x_ns = d->x_nstride; p.x_ps = d->x_pstride; p.y_ns = d->y_nstride; p.y_ps = d->y_pstride;
+  p.y2_ns = d->y2_nstride; p.y2_ps = d->y2_pstride; p.r_ns = d->res_nstride; p.r_ps = d->res_pstride;
+  hipStream_t st = (hipStream_t)stream;
+
+  if (p.Cout == 1) {
+    if (p.Cin % 32) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: Cout=1 path needs Cin %% 32 == 0");
+    const int lpp = p.Cin / 32;
+    const size_t lds = (size_t)p.Ktot * sizeof(float);
+    const int blocks = cdiv((long long)p.M * lpp, 256);
+    switch (lpp) {
+      case 1: hipLaunchKernelGGL(conv_cout1_kernel<1>, dim3(blocks), dim3(256), lds, st, p); break;
+      case 2: hipLaunchKernelGGL(conv_cout1_kernel<2>, dim3(blocks), dim3(256), lds, st, p); break;
+      case 4: hipLaunchKernelGGL(conv_cout1_kernel<4>, dim3(blocks), dim3(256), lds, st, p); break;
+      case 8: hipLaunchKernelGGL(conv_cout1_kernel<8>, dim3(blocks), dim3(256), lds, st, p); break;
+      default: return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: Cout=1 path supports Cin in {32,64,128,256}");
+    }
+    return check_launch("conv_cout1");
+  }
+  // tile selection: the 128x128 tile has the best MFMA:LDS ratio but needs >= ~1 workgroup per CU
+  const long long big = (long long)cdiv(p.M, 128) * cdiv(p.Cout, 128);
+  if (p.Cout <= 32) return launch_igemm<128, 32, 4, 1>(p, st);
+  if (p.Cout <= 64) {
+    if (cdiv(p.M, 128) >= 200) return launch_igemm<128, 64, 2, 2>(p, st);
+    return launch_igemm<64, 64, 2, 2>(p, st);
+  }
+  if (big >= 200) return launch_igemm<128, 128, 2, 2>(p, st);
+  return launch_igemm<64, 64, 2, 2>(p, st);
+}

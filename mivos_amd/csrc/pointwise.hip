@@ -1,0 +1,324 @@
+// HBM-bound element-wise / small-stencil kernels of the propagation path (gfx950).
+// All are memory-bound: 16-byte vector accesses where the layout allows, grid-stride loops capped
+// at ~8 workgroups per CU (cdna guide, Guideline 11 / Appendix B "Element-wise").
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace mivos {
+
+char *err_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static inline int grid_for(int64_t work_items, int block = 256) {
+  int64_t g = (work_items + block - 1) / block;
+  const int64_t cap = 256 * 8;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ---------------------------------------------------------------- maxpool 3x3 / 2 / pad 1, NHWC
+__global__ void maxpool3x3s2_kernel(const float *__restrict__ x, float *__restrict__ y, int N, int H, int W, int C4,
+                                    int Ho, int Wo) {
+  const int64_t total = (int64_t)N * Ho * Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    int64_t t = i / C4;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int ih = oh * 2 - 1 + dy;
+      if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int iw = ow * 2 - 1 + dx;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const f32x4 v = reinterpret_cast<const f32x4 *>(x)[(((int64_t)n * H + ih) * W + iw) * C4 + c];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    reinterpret_cast<f32x4 *>(y)[i] = m;
+  }
+}
+
+// ---------------------------------------------------------------- bilinear helpers (align_corners=False)
+// PyTorch area_pixel_compute_source_index: src = (dst + 0.5) * scale - 0.5, clamped at 0.
+__device__ __forceinline__ void bilin_coord(int dst, float scale, int in_size, int &i0, int &i1, float &l1) {
+  float s = ((float)dst + 0.5f) * scale - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+__global__ void upsample2x_add_kernel(const float *__restrict__ skip, int64_t skip_ns, const float *__restrict__ up,
+                                      float *__restrict__ out, int N, int h, int w, int C4) {
+  const int H = 2 * h, W = 2 * w;
+  const int64_t total = (int64_t)N * H * W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    int64_t t = i / C4;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilin_coord(y, 0.5f, h, y0, y1, ly);
+    bilin_coord(x, 0.5f, w, x0, x1, lx);
+    const f32x4 *u = reinterpret_cast<const f32x4 *>(up) + (int64_t)n * h * w * C4 + c;
+    const f32x4 v00 = u[((int64_t)y0 * w + x0) * C4], v01 = u[((int64_t)y0 * w + x1) * C4];
+    const f32x4 v10 = u[((int64_t)y1 * w + x0) * C4], v11 = u[((int64_t)y1 * w + x1) * C4];
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const f32x4 s = reinterpret_cast<const f32x4 *>(skip + (int64_t)n * skip_ns)[((int64_t)y * W + x) * C4 + c];
+    f32x4 o;
+    o.x = s.x + (hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x));
+    o.y = s.y + (hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y));
+    o.z = s.z + (hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z));
+    o.w = s.w + (hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w));
+    reinterpret_cast<f32x4 *>(out)[i] = o;
+  }
+}
+
+__global__ void resize_bilinear_kernel(const float *__restrict__ x, float *__restrict__ y, int planes, int h, int w,
+                                       int H, int W, int act) {
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const int64_t total = (int64_t)planes * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % W);
+    int64_t t = i / W;
+    const int oy = (int)(t % H);
+    const int pl = (int)(t / H);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilin_coord(oy, sy, h, y0, y1, ly);
+    bilin_coord(ox, sx, w, x0, x1, lx);
+    const float *s = x + (int64_t)pl * h * w;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    float v = hy * (hx * s[y0 * w + x0] + lx * s[y0 * w + x1]) + ly * (hx * s[y1 * w + x0] + lx * s[y1 * w + x1]);
+    if (act == 1) v = 1.f / (1.f + expf(-v));
+    y[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------- area pool 16x16 (one wave per output cell row-chunk)
+__global__ void area_pool16_kernel(const float *__restrict__ x, float *__restrict__ y, int planes, int H, int W) {
+  const int h = H / 16, w = W / 16;
+  const int64_t cells = (int64_t)planes * h * w;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t cell = wave; cell < cells; cell += nwaves) {
+    const int cx = (int)(cell % w);
+    int64_t t = cell / w;
+    const int cy = (int)(t % h);
+    const int pl = (int)(t / h);
+    // lane -> (row = lane/4, 4 consecutive pixels): one float4 per lane covers the 16x16 block
+    const int r = lane >> 2, q = lane & 3;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((int64_t)pl * H + cy * 16 + r) * W + cx * 16 + q * 4);
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) y[cell] = s * (1.f / 256.f);
+  }
+}
+
+// ---------------------------------------------------------------- aggregate (soft background / fixed background)
+template <bool WBG>
+__global__ void aggregate_kernel(const float *__restrict__ prob, float *__restrict__ out, int K, int64_t P, int keep_bg,
+                                 int hard) {
+  constexpr int KMAX = 32;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+    float l[KMAX + 1];
+    float bg = WBG ? 1.f : 0.5f;
+    float mx = -INFINITY;
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+      const float pk = prob[(int64_t)k * P + i];
+      if (WBG) bg *= (1.f - pk);
+      const float c = fminf(fmaxf(pk, 1e-7f), 1.f - 1e-7f);
+      float lg = logf(c / (1.f - c));
+      if (hard) lg *= 1000.f;
+      l[k + 1] = lg;
+      mx = fmaxf(mx, lg);
+    }
+    {
+      const float c = fminf(fmaxf(bg, 1e-7f), 1.f - 1e-7f);
+      float lg = logf(c / (1.f - c));
+      if (hard) lg *= 1000.f;
+      l[0] = lg;
+      mx = fmaxf(mx, lg);
+    }
+    float sum = 0.f;
+#pragma unroll 1
+    for (int k = 0; k <= K; ++k) {
+      l[k] = expf(l[k] - mx);
+      sum += l[k];
+    }
+    if (keep_bg) {
+      for (int k = 0; k <= K; ++k) out[(int64_t)k * P + i] = l[k] / sum;
+    } else {
+      for (int k = 1; k <= K; ++k) out[(int64_t)(k - 1) * P + i] = l[k] / sum;
+    }
+  }
+}
+
+__global__ void argmax_u8_kernel(const float *__restrict__ prob, int64_t plane_stride, uint8_t *__restrict__ out,
+                                 int planes, int64_t P) {
+  // 4 pixels per thread: float4 loads, one packed 32-bit store
+  const int64_t P4 = P >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 best = reinterpret_cast<const f32x4 *>(prob)[i];
+    uint32_t idx = 0;  // 4 x u8 lanes
+    for (int c = 1; c < planes; ++c) {
+      const f32x4 v = reinterpret_cast<const f32x4 *>(prob + (int64_t)c * plane_stride)[i];
+      if (v.x > best.x) { best.x = v.x; idx = (idx & 0xffffff00u) | (uint32_t)c; }
+      if (v.y > best.y) { best.y = v.y; idx = (idx & 0xffff00ffu) | ((uint32_t)c << 8); }
+      if (v.z > best.z) { best.z = v.z; idx = (idx & 0xff00ffffu) | ((uint32_t)c << 16); }
+      if (v.w > best.w) { best.w = v.w; idx = (idx & 0x00ffffffu) | ((uint32_t)c << 24); }
+    }
+    reinterpret_cast<uint32_t *>(out)[i] = idx;
+  }
+}
+
+__global__ void mask_diff_kernel(const float *__restrict__ mask, const float *__restrict__ prob, float *__restrict__ pos,
+                                 float *__restrict__ neg, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = mask[i] - prob[i];
+    pos[i] = fminf(fmaxf(d, 0.f), 1.f);
+    neg[i] = fminf(fmaxf(-d, 0.f), 1.f);
+  }
+}
+
+__global__ void sigmoid_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = 1.f / (1.f + expf(-x[i]));
+}
+
+__global__ void mask_others_kernel(const float *__restrict__ masks, float *__restrict__ others, int K, int64_t P) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int a = 0; a < K; ++a) {
+      float s = 0.f;  // torch.sum over the other objects, ascending object order (prop_net.py:151-155)
+      for (int b = 0; b < K; ++b)
+        if (b != a) s += masks[(int64_t)b * P + i];
+      others[(int64_t)a * P + i] = s;
+    }
+  }
+}
+
+__global__ void interleave_kernel(mivos_interleave_desc d, float *__restrict__ out, int N, int64_t P) {
+  const int C = d.C;
+  const int64_t total = (int64_t)N * P;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / P, px = i - n * P;
+    float *o = out + i * C;
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      f32x4 v;
+      float t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c0 + j;
+        t[j] = d.plane[c] ? d.plane[c][n * d.nstride[c] + px] : d.cval[c];
+      }
+      v.x = t[0]; v.y = t[1]; v.z = t[2]; v.w = t[3];
+      *reinterpret_cast<f32x4 *>(o + c0) = v;
+    }
+  }
+}
+
+}  // namespace mivos
+
+using namespace mivos;
+#define ST ((hipStream_t)stream)
+
+extern "C" int mivos_version(void) { return MIVOS_ABI_VERSION; }
+extern "C" const char *mivos_last_error(void) { return err_buf(); }
+
+extern "C" int mivos_device_check(int device) {
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return fail(MIVOS_ERR_DEVICE, "hipGetDeviceProperties(%d): %s", device, hipGetErrorString(e));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(MIVOS_ERR_DEVICE, "device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+  return MIVOS_OK;
+}
+
+extern "C" int mivos_maxpool3x3s2(const float *x, float *y, int N, int H, int W, int C, void *stream) {
+  if (!x || !y || C % 4 || N < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "maxpool: bad arguments (C %% 4 != 0?)");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for((int64_t)N * Ho * Wo * (C / 4))), dim3(256), 0, ST, x, y, N, H, W, C / 4, Ho, Wo);
+  return check_launch("maxpool3x3s2");
+}
+
+extern "C" int mivos_upsample2x_add(const float *skip, int64_t skip_nstride, const float *up, float *out, int N, int h,
+                                    int w, int C, void *stream) {
+  if (!skip || !up || !out || C % 4 || (skip_nstride & 3)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "upsample2x_add: bad arguments");
+  hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid_for((int64_t)N * 4 * h * w * (C / 4))), dim3(256), 0, ST, skip, skip_nstride, up, out, N, h, w, C / 4);
+  return check_launch("upsample2x_add");
+}
+
+extern "C" int mivos_area_pool16(const float *x, float *y, int planes, int H, int W, void *stream) {
+  if (!x || !y || H % 16 || W % 16) return fail(MIVOS_ERR_INVALID_ARGUMENT, "area_pool16: H, W must be multiples of 16");
+  const int64_t cells = (int64_t)planes * (H / 16) * (W / 16);
+  hipLaunchKernelGGL(area_pool16_kernel, dim3(grid_for(cells * 64)), dim3(256), 0, ST, x, y, planes, H, W);
+  return check_launch("area_pool16");
+}
+
+extern "C" int mivos_resize_bilinear(const float *x, float *y, int planes, int h, int w, int H, int W, int act,
+                                     void *stream) {
+  if (!x || !y || planes < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "resize_bilinear: bad arguments");
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for((int64_t)planes * H * W)), dim3(256), 0, ST, x, y, planes, h, w, H, W, act);
+  return check_launch("resize_bilinear");
+}
+
+extern "C" int mivos_aggregate_wbg(const float *prob, float *out, int K, int64_t P, int keep_bg, int hard, void *stream) {
+  if (!prob || !out || K < 1 || K > 32) return fail(MIVOS_ERR_INVALID_ARGUMENT, "aggregate_wbg: 1 <= K <= 32 required");
+  hipLaunchKernelGGL(aggregate_kernel<true>, dim3(grid_for(P)), dim3(256), 0, ST, prob, out, K, P, keep_bg, hard);
+  return check_launch("aggregate_wbg");
+}
+
+extern "C" int mivos_aggregate_sbg(const float *prob, float *out, int K, int64_t P, int keep_bg, int hard, void *stream) {
+  if (!prob || !out || K < 1 || K > 32) return fail(MIVOS_ERR_INVALID_ARGUMENT, "aggregate_sbg: 1 <= K <= 32 required");
+  hipLaunchKernelGGL(aggregate_kernel<false>, dim3(grid_for(P)), dim3(256), 0, ST, prob, out, K, P, keep_bg, hard);
+  return check_launch("aggregate_sbg");
+}
+
+extern "C" int mivos_argmax_u8(const float *prob, int64_t plane_stride, uint8_t *out, int planes, int64_t P, void *stream) {
+  if (!prob || !out || planes < 1 || planes > 255 || (P & 3) || (plane_stride & 3)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "argmax_u8: P and plane stride must be multiples of 4, planes <= 255");
+  hipLaunchKernelGGL(argmax_u8_kernel, dim3(grid_for(P / 4)), dim3(256), 0, ST, prob, plane_stride, out, planes, P);
+  return check_launch("argmax_u8");
+}
+
+extern "C" int mivos_mask_diff(const float *mask, const float *prob, float *pos, float *neg, int64_t n, void *stream) {
+  if (!mask || !prob || !pos || !neg) return fail(MIVOS_ERR_INVALID_ARGUMENT, "mask_diff: null pointer");
+  hipLaunchKernelGGL(mask_diff_kernel, dim3(grid_for(n)), dim3(256), 0, ST, mask, prob, pos, neg, n);
+  return check_launch("mask_diff");
+}
+
+extern "C" int mivos_sigmoid(const float *x, float *y, int64_t n, void *stream) {
+  if (!x || !y) return fail(MIVOS_ERR_INVALID_ARGUMENT, "sigmoid: null pointer");
+  hipLaunchKernelGGL(sigmoid_kernel, dim3(grid_for(n)), dim3(256), 0, ST, x, y, n);
+  return check_launch("sigmoid");
+}
+
+extern "C" int mivos_mask_others(const float *masks, float *others, int K, int64_t P, void *stream) {
+  if (!masks || !others || K < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "mask_others: bad arguments");
+  hipLaunchKernelGGL(mask_others_kernel, dim3(grid_for(P)), dim3(256), 0, ST, masks, others, K, P);
+  return check_launch("mask_others");
+}
+
+extern "C" int mivos_interleave_planes(const mivos_interleave_desc *d, float *out, int N, int64_t P, void *stream) {
+  if (!d || !out || d->C < 4 || d->C > 16 || d->C % 4) return fail(MIVOS_ERR_INVALID_ARGUMENT, "interleave_planes: C must be 4, 8, 12 or 16");
+  hipLaunchKernelGGL(interleave_kernel, dim3(grid_for((int64_t)N * P)), dim3(256), 0, ST, *d, out, N, P);
+  return check_launch("interleave_planes");
+}

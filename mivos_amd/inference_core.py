@@ -1,0 +1,232 @@
+"""InferenceCore for MI355X: bidirectional space-time-memory propagation + difference-aware fusion.
+
+Drop-in for the reference's `inference_core.py:17-293` (same constructor, ``interact`` /
+``update_mask_only`` / ``get_image_buffered``, same public attributes ``prob, masks, np_masks, images,
+pad, k, t, h, w, nh, nw``), re-designed around the HIP engine:
+
+  * the control flow of a pass is computed up front by ``plan_pass`` (pure Python, unit-tested
+    against the reference's golden schedule) and then executed;
+  * the memory bank is one pre-allocated ``[K, slots, h, w, C]`` buffer per pass; ``memorize`` writes
+    its keys/values straight into the slot from the KeyValue GEMM epilogue (no copy), the reader gets
+    ``bank[:, :n]`` as strides;
+  * per-frame query features are cached together with the object-independent decoder skip branches,
+    so re-propagation after a later interaction skips 128 GMAC/frame of encoder + skip work;
+  * fusion runs all K objects as one batch (one attention launch, one FusionNet chain);
+  * the final argmax over all T frames is a single launch.
+"""
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .model.fusion_net import FusionNet
+from .model.propagation.prop_net import CK, CV, PropagationNetwork
+from .util.tensor_util import pad_divide_by
+
+Step = namedtuple("Step", "ti n_read slot fuse")
+
+
+def plan_pass(t, interacted, idx, forward, mem_freq, n_certain):
+    """Schedule of one propagation pass (reference: do_pass, inference_core.py:122-200).
+
+    Returns (closest, total_slots, steps).  Each step: frame index ``ti``, number of leading bank
+    slots the reader sees (``n_read``), the slot the frame's own key/value are written to afterwards
+    (``None`` for the last frame of the pass) and whether the frame is fused.  Every propagated frame is
+    written to the slot at the front (a temporary 'previous frame' memory); the front only advances
+    — i.e. the frame is kept — when it is at least ``mem_freq`` frames from the last kept one."""
+    if forward:
+        closest = min([x for x in interacted if x > idx] + [t])
+        frames = list(range(idx + 1, closest))
+    else:
+        closest = max([x for x in interacted if x < idx] + [-1])
+        frames = list(range(idx - 1, closest, -1))
+    total = len(frames) // mem_freq + 1 + n_certain
+    fuse = closest != t and closest != -1
+    steps, front, last_kept, prev_kept = [], n_certain, idx, True
+    for i, ti in enumerate(frames):
+        n_read = front if prev_kept else front + 1
+        slot = None
+        if i != len(frames) - 1:
+            slot = front
+            prev_kept = abs(ti - last_kept) >= mem_freq
+            if prev_kept:
+                front, last_kept = front + 1, ti
+        steps.append(Step(ti, n_read, slot, fuse))
+    return closest, total, steps
+
+
+class InferenceCore:
+    """
+    images       - unpadded, normalised CPU tensor [1,T,3,H,W]
+    mem_profile  - 0: everything resident in HBM (default; a 1080p x 1000-frame clip is ~70 GB of the
+                   288 GB).  1-3 keep images (and for 2-3 results) on the host with bounded caches,
+                   like the reference (inference_core.py:44-63); accuracy is unaffected.
+    mem_freq     - every mem_freq-th propagated frame is kept in the memory bank
+    """
+
+    def __init__(self, prop_net: PropagationNetwork, fuse_net: FusionNet, images, num_objects,
+                 mem_profile=0, mem_freq=5, device="cuda:0"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ops.MivosHipError("InferenceCore needs an MI355X device; mivos_amd has no CPU execution path")
+        self.prop_net = prop_net.to(self.device)
+        if fuse_net is not None:
+            self.fuse_net = fuse_net.to(self.device)
+        self.mem_profile, self.mem_freq = mem_profile, mem_freq
+        self.data_dev = self.device if mem_profile == 0 else torch.device("cpu")
+        self.result_dev = self.device if mem_profile in (0, 1) else torch.device("cpu")
+        self.q_buf_size = {0: 105, 1: 105, 2: 3}.get(mem_profile, 1)
+        self.i_buf_size = {0: -1, 1: 105, 2: 3}.get(mem_profile, 1)
+
+        self.t = images.shape[1]
+        self.h, self.w = images.shape[-2:]
+        self.k = num_objects
+        self.images, self.pad = pad_divide_by(images, 16, images.shape[-2:])
+        self.nh, self.nw = self.images.shape[-2:]
+        self.images = self.images.to(self.data_dev)
+        self.kh, self.kw = self.nh // 16, self.nw // 16
+
+        self.masks = torch.zeros((self.t, 1, self.nh, self.nw), dtype=torch.uint8, device=self.result_dev)
+        self.np_masks = np.zeros((self.t, self.h, self.w), dtype=np.uint8)
+        self.prob = torch.zeros((self.k + 1, self.t, 1, self.nh, self.nw), dtype=torch.float32, device=self.result_dev)
+        self.prob[0] = 1e-7
+
+        self.query_buf, self.image_buf = {}, {}
+        self.interacted = set()
+        self._certain_k = self._certain_v = None     # [K, n, h, w, C] rows per memory position
+        self.propagated_frames = 0                   # do_pass iterations so far (the bench metric)
+
+    # ---- reference-shaped views of the certain memory -------------------------------------
+    @property
+    def certain_mem_k(self):
+        return None if self._certain_k is None else self._certain_k.permute(0, 4, 1, 2, 3)
+
+    @property
+    def certain_mem_v(self):
+        return None if self._certain_v is None else self._certain_v.permute(0, 4, 1, 2, 3)
+
+    # ---- caches -----------------------------------------------------------------------------
+    def get_image_buffered(self, idx):
+        if self.data_dev == self.device:
+            return self.images[:, idx]
+        if idx not in self.image_buf:
+            if len(self.image_buf) > self.i_buf_size:
+                self.image_buf = {}
+            self.image_buf[idx] = self.images[:, idx].to(self.device)
+        return self.image_buf[idx]
+
+    def _query(self, idx):
+        q = self.query_buf.get(idx)
+        if q is None:
+            if len(self.query_buf) > self.q_buf_size:
+                self.query_buf = {}
+            q = self.query_buf[idx] = self.prop_net.encode_query(self.get_image_buffered(idx))
+        return q
+
+    def get_query_kv_buffered(self, idx):
+        return self._query(idx).as_reference_tuple()
+
+    # ---- one propagation pass ---------------------------------------------------------------
+    def do_pass(self, key_k, key_v, idx, forward=True, step_cb=None):
+        """key_k: keys of the interacted frame, rows layout [K, h*w, 128] (used by the fusion attention)."""
+        nc = self._certain_k.shape[1]
+        closest, total, steps = plan_pass(self.t, self.interacted, idx, forward, self.mem_freq, nc)
+        if not steps:
+            return closest
+        K, kh, kw = self.k, self.kh, self.kw
+        keys = torch.empty((K, total, kh, kw, CK), dtype=torch.float32, device=self.device)
+        values = torch.empty((K, total, kh, kw, CV), dtype=torch.float32, device=self.device)
+        keys[:, :nc], values[:, :nc] = self._certain_k, self._certain_v
+        hw = kh * kw
+        for st in steps:
+            q = self._query(st.ti)
+            prob_k = self.prop_net.segment(keys[:, :st.n_read].reshape(K, st.n_read * hw, CK),
+                                           values[:, :st.n_read].reshape(K, st.n_read * hw, CV), q)
+            out = ops.aggregate(prob_k.unsqueeze(1), keep_bg=True)            # [K+1,1,nh,nw]
+            if st.slot is not None:
+                self.prop_net.memorize_into(self.get_image_buffered(st.ti), out[1:],
+                                            key_out=keys[:, st.slot], val_out=values[:, st.slot])
+            if st.fuse:
+                out = self.fuse_one_frame(closest, idx, st.ti, self.prob[:, st.ti], out, key_k, q.k16)
+            self.prob[:, st.ti] = out.to(self.result_dev)
+            self.propagated_frames += 1
+            if step_cb is not None:
+                step_cb()
+        return closest
+
+    def fuse_one_frame(self, tc, tr, ti, prev_mask, curr_mask, mk16, qk16):
+        """Difference-aware fusion of the previous result with the new propagation for frame ti
+        (reference inference_core.py:202-217), all K objects in one batch.  mk16: [K, h*w, 128] rows or
+        the reference's [K,128,1,h,w]; qk16: NHWC [1,h,w,128] or the reference's [1,128,h,w]."""
+        assert tc < ti < tr or tr < ti < tc
+        K, P = self.k, self.nh * self.nw
+        nc, nr = abs(tc - ti) / abs(tc - tr), abs(tr - ti) / abs(tc - tr)
+        if mk16.dim() == 5:          # called the reference's way: NCHW-shaped key / query tensors
+            mk16 = mk16.permute(0, 2, 3, 4, 1).reshape(K, -1, CK)
+            qk16 = qk16.permute(0, 2, 3, 1)
+        hw = self.kh * self.kw
+        low = self.prop_net.attention_lowres(mk16, self._pos16, self._neg16, qk16.reshape(hw, CK))
+        attn = ops.resize_bilinear(low.view(K * 2, self.kh, self.kw), self.nh, self.nw)      # [2K, nh, nw]
+        prev = prev_mask.to(self.device)
+        curr = curr_mask.to(self.device)
+        im = self.get_image_buffered(ti).contiguous()
+        prev_k, curr_k = prev[1:], curr[1:]
+        x = self.fuse_net.pack_inputs((im, 0), (prev_k, prev_k.stride(0)), (curr_k, curr_k.stride(0)),
+                                      (attn, 2 * P), (nc, nr), K)
+        w = ops.sigmoid(self.fuse_net.run(x))                                               # [K,nh,nw,1]
+        return ops.aggregate(w.view(K, 1, self.nh, self.nw), keep_bg=True)
+
+    # ---- public entry points ------------------------------------------------------------------
+    def interact(self, mask, idx, total_cb=None, step_cb=None):
+        """mask: one-hot [K+1,1,H,W] (background first) of frame idx.  Propagates both ways from idx,
+        fusing with earlier results between interacted frames.  Returns uint8 [T,H,W]."""
+        self.interacted.add(idx)
+        mask = mask.to(self.device).float()
+        mask, _ = pad_divide_by(mask, 16, mask.shape[-2:])
+        mask = mask.contiguous()
+        old = self.prob[:, idx].to(self.device)
+        self.pos_mask_diff, self.neg_mask_diff = ops.mask_diff(mask, old)
+        # 1/16-resolution difference maps are the same for every fused frame of this interaction
+        K = self.k
+        self._pos16 = ops.area_pool16(self.pos_mask_diff[1:].reshape(K, self.nh, self.nw)).view(K, -1)
+        self._neg16 = ops.area_pool16(self.neg_mask_diff[1:].reshape(K, self.nh, self.nw)).view(K, -1)
+        self.prob[:, idx] = mask.to(self.result_dev)
+
+        key_k, key_v = self.prop_net.memorize_into(self.get_image_buffered(idx), mask[1:])   # [K,h,w,C]
+        key_k5, key_v5 = key_k.unsqueeze(1), key_v.unsqueeze(1)
+        if self._certain_k is None:
+            self._certain_k, self._certain_v = key_k5, key_v5
+        else:
+            self._certain_k = torch.cat([self._certain_k, key_k5], 1)
+            self._certain_v = torch.cat([self._certain_v, key_v5], 1)
+
+        if total_cb is not None:
+            front = min([ti for ti in self.interacted if ti > idx] + [self.t])
+            back = max([ti for ti in self.interacted if ti < idx] + [-1])
+            if front - back - 2 > 0:
+                total_cb(front - back - 2)
+
+        rows = key_k.reshape(K, self.kh * self.kw, CK)
+        self.do_pass(rows, key_v, idx, True, step_cb=step_cb)
+        self.do_pass(rows, key_v, idx, False, step_cb=step_cb)
+        return self._refresh_masks()
+
+    def _refresh_masks(self):
+        """argmax over objects for every frame (one launch), crop the padding, copy to the host."""
+        prob = self.prob if self.prob.device == self.device else self.prob.to(self.device)
+        m = ops.argmax_u8(prob.view(self.k + 1, self.t * self.nh * self.nw)).view(self.t, 1, self.nh, self.nw)
+        self.masks = m.to(self.result_dev)
+        l, r, t, b = self.pad
+        out = m[:, 0, t:self.nh - b, l:self.nw - r]
+        self.np_masks = out.cpu().numpy().astype(np.uint8)
+        return self.np_masks
+
+    def update_mask_only(self, prob_mask, idx):
+        """Interaction without propagation (reference :273-293): prob_mask [K+1,1,nh,nw] (padded)."""
+        prob_mask = prob_mask.to(self.device).float().contiguous()
+        m = ops.argmax_u8(prob_mask.view(prob_mask.shape[0], -1)).view(1, self.nh, self.nw)
+        self.masks[idx] = m.to(self.result_dev)
+        l, r, t, b = self.pad
+        self.np_masks[idx] = m[0, t:self.nh - b, l:self.nw - r].cpu().numpy().astype(np.uint8)
+        return self.np_masks

@@ -1,0 +1,71 @@
+"""Difference-aware FusionNet for MI355X — interface of the reference's `model/fusion_net.py:8-50`
+(same constructor, forward signature and 12-key state_dict), run as fused NHWC implicit-GEMM
+convolutions (bias + residual + ReLU in the GEMM epilogue, 32->1 head as a dot-product kernel).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import MivosHipError
+from .propagation.modules import ConvParams
+
+
+class FusionNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Sequential(ConvParams(9, 32, 3, padding=1), nn.ReLU())
+        self.conv2 = nn.Sequential(ConvParams(32, 32, 3, padding=1), nn.ReLU(), ConvParams(32, 32, 3, padding=1))
+        self.conv3 = nn.Sequential(ConvParams(32, 32, 3, padding=1), nn.ReLU(), ConvParams(32, 32, 3, padding=1))
+        self.relu = nn.ReLU()
+        self.final_conv = ConvParams(32, 1, 3, padding=1)
+        self._plan = None
+
+    def _apply(self, fn, *a, **k):
+        self._plan = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._plan = None
+        return super().load_state_dict(*a, **k)
+
+    def plan(self):
+        if self._plan is None:
+            if self.final_conv.weight.device.type != "cuda":
+                raise MivosHipError("FusionNet must live on an MI355X; mivos_amd has no CPU execution path")
+            with torch.no_grad():
+                self._plan = (self.conv1[0].pack(cin_pad=16), self.conv2[0].pack(), self.conv2[2].pack(),
+                              self.conv3[0].pack(), self.conv3[2].pack(), self.final_conv.pack())
+        return self._plan
+
+    def run(self, x):
+        """x NHWC [B,H,W,16] (9 real channels: im, seg1, seg2, attn(2), time(2)) -> logits [B,H,W,1]."""
+        c1, c2a, c2b, c3a, c3b, fin = self.plan()
+        x = ops.conv(x, c1, relu_out=True)
+        r = ops.conv(x, c2a, relu_out=True)
+        x = ops.conv(r, c2b, res=x, relu_out=True)        # relu(x + conv2(x))   fusion_net.py:42-43
+        r = ops.conv(x, c3a, relu_out=True)
+        x = ops.conv(r, c3b, res=x, relu_out=True)        # relu(x + conv3(x))   fusion_net.py:45-46
+        return ops.conv(x, fin)
+
+    def pack_inputs(self, im, seg1, seg2, attn, time_pair, batch):
+        """Channel-concatenate planar inputs into NHWC16.  Each of im/seg1/seg2/attn is
+        (tensor, batch_stride_in_elements); time_pair is (nc, nr) python floats."""
+        (im_t, im_s), (s1_t, s1_s), (s2_t, s2_s), (at_t, at_s) = im, seg1, seg2, attn
+        H, W = im_t.shape[-2:]
+        P = H * W
+        imf, atf = im_t.reshape(-1), at_t.reshape(-1)
+        planes = [(imf[c * P:], im_s) for c in range(3)] + [(s1_t, s1_s), (s2_t, s2_s)]
+        planes += [(atf[c * P:], at_s) for c in range(2)] + [(float(time_pair[0]), 0), (float(time_pair[1]), 0)]
+        return ops.interleave(planes, batch, P, 16, im_t.device).view(batch, H, W, 16)
+
+    def forward(self, im, seg1, seg2, attn, time):
+        B, _, H, W = im.shape
+        P = H * W
+        im, seg1, seg2, attn = (t.contiguous().float() for t in (im, seg1, seg2, attn))
+        outs = []
+        tl = time.detach().float().cpu().tolist()
+        for b in range(B):   # per-sample constant time planes (B == 1 on the inference path)
+            x = self.pack_inputs((im[b], 0), (seg1[b], 0), (seg2[b], 0), (attn[b], 0), tl[b], 1)
+            outs.append(self.run(x))
+        y = outs[0] if B == 1 else torch.cat(outs, 0)
+        return y.permute(0, 3, 1, 2)

@@ -1,0 +1,207 @@
+"""PropagationNetwork for MI355X — same public surface as the reference's
+`model/propagation/prop_net.py:131-200` (memorize / get_query_values / segment_with_query /
+get_W / get_attention, ``top_k`` constructor argument, 597-key state_dict), executed by
+hand-written HIP kernels through libmivos_hip.so.
+
+Layout.  Public methods take and return tensors with the reference's *logical* shapes
+(NCHW, keys ``[K,128,T,h,w]`` ...).  Physically everything is channels-last: a returned
+``[N,C,H,W]`` tensor is a zero-copy permuted view of an NHWC buffer, and memory keys/values are
+rows of 128/512 floats per memory position (``[K,T,h,w,C]``), which is what the affinity MFMA
+tiles and the sparse value gather want.  Inputs in any other layout are converted on entry.
+
+``InferenceCore`` uses the internal fast path (``encode_query`` / ``memorize_into`` /
+``segment``) that also caches the object-independent decoder skip branches per frame.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..._lib import MivosHipError
+from .modules import (ConvParams, KeyValue, MaskRGBEncoder, ResBlock, RGBEncoder, UpsampleBlock,
+                      run_resblock, run_skip_branch, run_trunk, run_up_branch)
+
+CK, CV = 128, 512
+
+
+class Decoder(nn.Module):
+    """prop_net.py:14-31."""
+
+    def __init__(self):
+        super().__init__()
+        self.compress = ResBlock(1024, 512)
+        self.up_16_8 = UpsampleBlock(512, 512, 256)
+        self.up_8_4 = UpsampleBlock(256, 256, 256)
+        self.pred = ConvParams(256, 1, 3, padding=1)
+
+    def compile(self):
+        return dict(compress=self.compress.compile(), up_16_8=self.up_16_8.compile(),
+                    up_8_4=self.up_8_4.compile(), pred=self.pred.pack())
+
+
+class EvalMemoryReader(nn.Module):
+    """prop_net.py:75-108 (km=None): fused affinity + top-k softmax + readout."""
+
+    def __init__(self, top_k, km=None):
+        super().__init__()
+        if km is not None:
+            raise NotImplementedError("kernelised memory (km) is not used by the reference's inference path")
+        self.top_k, self.km = top_k, km
+
+    def forward(self, mk, mv, qk):
+        B, _, T, H, W = mk.shape
+        keys = mk.permute(0, 2, 3, 4, 1).reshape(B, T * H * W, CK)
+        vals = mv.permute(0, 2, 3, 4, 1).reshape(B, T * H * W, CV)
+        q = qk.permute(0, 2, 3, 1).reshape(H * W, CK).contiguous()
+        out = ops.memory_read(keys, vals, q, self.top_k)            # [B, HW, 512]
+        return out.view(B, H, W, CV).permute(0, 3, 1, 2)
+
+
+class AttentionMemory(nn.Module):
+    """prop_net.py:110-129.  The [HW x HW] softmax matrix is only materialised if somebody asks
+    for it through get_W(); get_attention() uses the fused kernel."""
+
+    def __init__(self, k):
+        super().__init__()
+        self.k = k
+
+    def forward(self, mk, qk):
+        raise MivosHipError("AttentionMemory.forward (dense W) is not on the MI355X path; use "
+                            "PropagationNetwork.get_attention, which fuses W into the pos/neg products")
+
+
+class QueryFeatures:
+    """Per-frame query features, NHWC.  s8 / s4 (decoder skip branches, object independent) are
+    filled lazily by PropagationNetwork._skip()."""
+    __slots__ = ("f16", "f8", "f4", "k16", "v16", "s8", "s4")
+
+    def __init__(self, f16, f8, f4, k16, v16):
+        self.f16, self.f8, self.f4, self.k16, self.v16 = f16, f8, f4, k16, v16
+        self.s8 = self.s4 = None
+
+    def as_reference_tuple(self):
+        return tuple(t.permute(0, 3, 1, 2) for t in (self.f16, self.f8, self.f4, self.k16, self.v16))
+
+
+def _nhwc(t):
+    """logical NCHW tensor -> NHWC tensor with unit channel stride (zero-copy when already channels-last)."""
+    x = t.permute(0, 2, 3, 1)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+class PropagationNetwork(nn.Module):
+    def __init__(self, top_k=50):
+        super().__init__()
+        self.mask_rgb_encoder = MaskRGBEncoder()
+        self.rgb_encoder = RGBEncoder()
+        self.kv_m_f16 = KeyValue(1024, keydim=CK, valdim=CV)
+        self.kv_q_f16 = KeyValue(1024, keydim=CK, valdim=CV)
+        self.memory = EvalMemoryReader(top_k, km=None)
+        self.attn_memory = AttentionMemory(top_k)
+        self.decoder = Decoder()
+        self._plan = None
+
+    # ---- compiled-plan management -------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._plan = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._plan = None
+        return super().load_state_dict(*a, **k)
+
+    def plan(self):
+        if self._plan is None:
+            dev = self.kv_q_f16.key_proj.weight.device
+            if dev.type != "cuda":
+                raise MivosHipError("PropagationNetwork must live on an MI355X (call .cuda() / .to('cuda:0')); "
+                                    "mivos_amd has no CPU execution path")
+            with torch.no_grad():
+                self._plan = dict(menc=self.mask_rgb_encoder.compile(), qenc=self.rgb_encoder.compile(),
+                                  kv_m=self.kv_m_f16.compile(), kv_q=self.kv_q_f16.compile(),
+                                  dec=self.decoder.compile())
+        return self._plan
+
+    # ---- internal fast path (NHWC) ------------------------------------------------------
+    def encode_query(self, frame):
+        """frame [1,3,H,W] (planar, normalised) -> QueryFeatures."""
+        p = self.plan()
+        _, _, H, W = frame.shape
+        frame = frame.contiguous()
+        x = ops.interleave([(frame[0, c], 0) for c in range(3)], 1, H * W, 4, frame.device).view(1, H, W, 4)
+        f16, f8, f4 = run_trunk(p["qenc"], x)
+        k16, v16 = ops.conv(f16, p["kv_q"])
+        return QueryFeatures(f16, f8, f4, k16, v16)
+
+    def _skip(self, q):
+        if q.s8 is None:
+            dec = self.plan()["dec"]
+            q.s8 = run_skip_branch(dec["up_16_8"], q.f8)
+            q.s4 = run_skip_branch(dec["up_8_4"], q.f4)
+        return q.s8, q.s4
+
+    def memorize_into(self, frame, masks, key_out=None, val_out=None):
+        """frame [1,3,H,W], masks [K,1,H,W] -> keys [K,h,w,128], values [K,h,w,512] (NHWC), written
+        straight into key_out / val_out (e.g. a memory-bank slot view) when given."""
+        p = self.plan()
+        K, _, H, W = masks.shape
+        frame, masks = frame.contiguous(), masks.contiguous().float()
+        others = ops.mask_others(masks) if K > 1 else torch.zeros_like(masks)
+        P = H * W
+        planes = [(frame[0, c], 0) for c in range(3)] + [(masks, P), (others, P)]
+        x = ops.interleave(planes, K, P, 8, frame.device).view(K, H, W, 8)
+        f16, _, _ = run_trunk(p["menc"], x)
+        return ops.conv(f16, p["kv_m"], out=key_out, out2=val_out)
+
+    def segment(self, keys, values, q, logits=False):
+        """keys [K,n_mem,128], values [K,n_mem,512] (rows per memory position), q QueryFeatures ->
+        object probabilities [K,H,W] (sigmoid applied, prop_net.py:181) or raw logits."""
+        dec = self.plan()["dec"]
+        K = keys.shape[0]
+        _, h, w, _ = q.f16.shape
+        s8, s4 = self._skip(q)
+        m4 = torch.empty((K, h, w, 2 * CV), dtype=torch.float32, device=keys.device)
+        ops.memory_read(keys, values, q.k16.view(h * w, CK), self.memory.top_k, out=m4.view(K, h * w, 2 * CV)[:, :, :CV])
+        m4[..., CV:] = q.v16                                            # cat([mem, v16.expand(K)]) (prop_net.py:178-179)
+        x = run_resblock(dec["compress"], m4)
+        x = run_up_branch(dec["up_16_8"], s8, x)
+        x = run_up_branch(dec["up_8_4"], s4, x)
+        lo = ops.conv(x, dec["pred"], relu_in=True)                     # [K, H/4, W/4, 1]
+        return ops.resize_bilinear(lo.view(K, lo.shape[1], lo.shape[2]), 4 * lo.shape[1], 4 * lo.shape[2],
+                                   act=0 if logits else 1)
+
+    def attention_lowres(self, mk, pos16, neg16, qk16):
+        """mk [K,HW,128], pos16/neg16 [K,HW], qk16 [HW,128] -> [K,2,HW] aligned difference maps."""
+        return ops.attention_align(mk, qk16, pos16, neg16)
+
+    # ---- reference-compatible public API (logical NCHW) -----------------------------------
+    def memorize(self, frame, masks):
+        k, _, h, w = masks.shape
+        k16, v16 = self.memorize_into(frame.view(1, 3, h, w), masks)
+        return k16.permute(0, 3, 1, 2).unsqueeze(2), v16.permute(0, 3, 1, 2).unsqueeze(2)
+
+    def get_query_values(self, frame):
+        return self.encode_query(frame).as_reference_tuple()
+
+    def segment_with_query(self, keys, values, f16, f8, f4, k16, v16):
+        K, _, T, h, w = keys.shape
+        q = QueryFeatures(*(_nhwc(t) for t in (f16, f8, f4, k16, v16)))
+        kr = keys.permute(0, 2, 3, 4, 1).reshape(K, T * h * w, CK)
+        vr = values.permute(0, 2, 3, 4, 1).reshape(K, T * h * w, CV)
+        prob = self.segment(kr, vr, q)
+        return prob.unsqueeze(1)
+
+    def get_W(self, mk16, qk):
+        return self.attn_memory(mk16, qk)
+
+    def get_attention(self, mk16, pos_mask, neg_mask, qk16):
+        b, _, h, w = pos_mask.shape
+        nh, nw = h // 16, w // 16
+        mk = mk16.permute(0, 2, 3, 4, 1).reshape(b, nh * nw, CK)
+        qk = _nhwc(qk16).reshape(nh * nw, CK)
+        pos = ops.area_pool16(pos_mask.reshape(b, h, w)).view(b, nh * nw)
+        neg = ops.area_pool16(neg_mask.reshape(b, h, w)).view(b, nh * nw)
+        low = self.attention_lowres(mk, pos, neg, qk)                   # [b, 2, nh*nw]
+        return ops.resize_bilinear(low.view(b * 2, nh, nw), h, w).view(b, 2, h, w)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("use memorize / get_query_values / segment_with_query / get_attention")

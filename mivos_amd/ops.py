@@ -1,0 +1,308 @@
+"""Thin tensor-level wrappers over the C ABI (include/mivos_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every arithmetic op below is
+one call into libmivos_hip.so with raw device pointers.  Activations are fp32 NHWC tensors
+``[N, H, W, C]`` whose channel axis has stride 1; channel slices / batch-strided views (memory-bank
+slots) are passed as strides, never copied.  CPU tensors are rejected: there is no fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, InterleaveDesc, MivosHipError, check
+
+_checked_devices = set()
+
+
+def _ensure_device(t):
+    if not t.is_cuda:
+        raise MivosHipError("mivos_amd runs on MI355X (gfx950) only and has no CPU fallback; got a CPU tensor")
+    idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    if idx not in _checked_devices:
+        check(_lib.load().mivos_device_check(idx))
+        _checked_devices.add(idx)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise MivosHipError(f"expected float32, got {t.dtype}")
+    return t
+
+
+def _nhwc_strides(t):
+    """(nstride, pstride) of an NHWC view with dense rows; raises if the view is not expressible."""
+    n, h, w, c = t.shape
+    sn, sh, sw, sc = t.stride()
+    if c > 1 and sc != 1:
+        raise MivosHipError("NHWC tensor must have channel stride 1")
+    if h > 1 and sh != w * sw:
+        raise MivosHipError("NHWC tensor must have dense rows (stride_h == W * stride_w)")
+    return (sn if n > 1 else h * w * sw), sw
+
+
+class ConvLayer:
+    """Device-resident packed convolution: OHWI weights (+ folded BN scale / bias)."""
+    __slots__ = ("w", "scale", "bias", "cin", "cout", "k", "stride", "pad", "split")
+
+    def __init__(self, w_ohwi, scale, bias, stride, pad, split=None):
+        self.w = w_ohwi.contiguous()
+        self.cout, self.k, _, self.cin = w_ohwi.shape
+        self.scale, self.bias = scale, bias
+        self.stride, self.pad = stride, pad
+        self.split = self.cout if split is None else split
+
+    @staticmethod
+    def pack(weight, bias=None, bn=None, stride=1, pad=0, cin_pad=None, eps=1e-5):
+        """weight [Cout,Cin,k,k] (+conv bias) (+ eval BatchNorm (gamma, beta, mean, var)) ->
+        y = conv(x, w) * scale + bias'.   BN(conv + b) = conv*s + (b - mean)*s + beta, s = gamma/sqrt(var+eps)."""
+        w = weight.detach().float()
+        cout, cin = w.shape[:2]
+        if cin_pad is not None and cin_pad > cin:
+            w = torch.cat([w, w.new_zeros(cout, cin_pad - cin, *w.shape[2:])], 1)
+        w = w.permute(0, 2, 3, 1).contiguous()
+        b = bias.detach().float() if bias is not None else None
+        if bn is not None:
+            gamma, beta, mean, var = (t.detach().float() for t in bn)
+            s = gamma / torch.sqrt(var + eps)
+            b2 = beta - mean * s if b is None else (b - mean) * s + beta
+            return ConvLayer(w, s.contiguous(), b2.contiguous(), stride, pad)
+        return ConvLayer(w, None, None if b is None else b.contiguous(), stride, pad)
+
+    @staticmethod
+    def fuse_outputs(a, b):
+        """One GEMM for two convolutions of the same input (KeyValue: key_proj | val_proj)."""
+        assert a.k == b.k and a.cin == b.cin and a.stride == b.stride and a.scale is None and b.scale is None
+        bias = None
+        if a.bias is not None:
+            bias = torch.cat([a.bias, b.bias]).contiguous()
+        return ConvLayer(torch.cat([a.w, b.w], 0), None, bias, a.stride, a.pad, split=a.cout)
+
+    def to(self, device):
+        for n in ("w", "scale", "bias"):
+            v = getattr(self, n)
+            if v is not None:
+                setattr(self, n, v.to(device))
+        return self
+
+
+def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None):
+    """y = act(conv(act_in(x)) * scale + bias + res).  x [N,H,W,Cin] view; returns out (and out2 when the
+    layer is split, i.e. (out, out2))."""
+    _ensure_device(x)
+    n, h, w, cin = x.shape
+    if cin != L.cin:
+        raise MivosHipError(f"conv: input has {cin} channels, layer expects {L.cin}")
+    ho = (h + 2 * L.pad - L.k) // L.stride + 1
+    wo = (w + 2 * L.pad - L.k) // L.stride + 1
+    dual = L.split < L.cout
+    if out is None:
+        out = torch.empty((n, ho, wo, L.split), dtype=torch.float32, device=x.device)
+    if dual and out2 is None:
+        out2 = torch.empty((n, ho, wo, L.cout - L.split), dtype=torch.float32, device=x.device)
+    d = ConvDesc()
+    d.x, d.w = _f32(x).data_ptr(), L.w.data_ptr()
+    d.scale = L.scale.data_ptr() if L.scale is not None else None
+    d.bias = L.bias.data_ptr() if L.bias is not None else None
+    d.y = out.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = n, h, w, cin, L.cout, L.k, L.k
+    d.stride, d.pad, d.Ho, d.Wo, d.split = L.stride, L.pad, ho, wo, L.split
+    d.relu_in, d.relu_out = int(relu_in), int(relu_out)
+    d.x_nstride, d.x_pstride = _nhwc_strides(x)
+    assert out.shape == (n, ho, wo, L.split), (out.shape, (n, ho, wo, L.split))
+    d.y_nstride, d.y_pstride = _nhwc_strides(out)
+    if dual:
+        assert out2.shape == (n, ho, wo, L.cout - L.split)
+        d.y2 = out2.data_ptr()
+        d.y2_nstride, d.y2_pstride = _nhwc_strides(out2)
+    if res is not None:
+        assert res.shape[1:] == (ho, wo, L.cout) and res.shape[0] in (1, n)
+        d.res = _f32(res).data_ptr()
+        rn, rp = _nhwc_strides(res)
+        d.res_nstride, d.res_pstride = (0 if (res.shape[0] == 1 and n > 1) else rn), rp
+    check(_lib.load().mivos_conv2d_fused(C.byref(d), _stream()))
+    return (out, out2) if dual else out
+
+
+def maxpool3x3s2(x):
+    _ensure_device(x)
+    n, h, w, c = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
+    check(_lib.load().mivos_maxpool3x3s2(x.data_ptr(), y.data_ptr(), n, h, w, c, _stream()))
+    return y
+
+
+def upsample2x_add(skip, up):
+    """skip [1 or N, 2h, 2w, C] + bilinear_x2(up [N, h, w, C])."""
+    _ensure_device(up)
+    n, h, w, c = up.shape
+    assert up.is_contiguous() and skip.is_contiguous() and skip.shape[1:] == (2 * h, 2 * w, c)
+    out = torch.empty((n, 2 * h, 2 * w, c), dtype=torch.float32, device=up.device)
+    sn = 0 if (skip.shape[0] == 1 and n > 1) else skip.stride(0)
+    check(_lib.load().mivos_upsample2x_add(skip.data_ptr(), sn, up.data_ptr(), out.data_ptr(), n, h, w, c, _stream()))
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _rows(t, width):
+    """[n_obj, n_rows, width] view whose rows are dense -> (tensor, object stride)."""
+    assert t.dim() == 3 and t.shape[2] == width
+    if t.stride(2) != 1 or t.stride(1) != width:
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else t.shape[1] * width)
+
+
+def memory_read(keys, values, qk, top_k, out=None):
+    """keys [K, n_mem, 128], values [K, n_mem, 512], qk [n_q, 128] -> out [K, n_q, 512]
+    (out may be a channel-slice view [K, n_q, 512] of a wider [K, n_q, C] buffer)."""
+    _ensure_device(keys)
+    keys, ko = _rows(_f32(keys), 128)
+    values, vo = _rows(_f32(values), 512)
+    k, n_mem, _ = keys.shape
+    n_q = qk.shape[0]
+    assert qk.is_contiguous() and qk.shape[1] == 128 and values.shape[:2] == (k, n_mem)
+    if top_k is None:
+        raise MivosHipError("memory_read: top_k=None (full softmax) is not part of the propagation path")
+    if out is None:
+        out = torch.empty((k, n_q, 512), dtype=torch.float32, device=keys.device)
+    assert out.shape == (k, n_q, 512) and out.stride(2) == 1
+    lib = _lib.load()
+    nbytes = lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k)
+    ws = _workspace(nbytes, keys.device)
+    check(lib.mivos_memory_read_topk(keys.data_ptr(), ko, values.data_ptr(), vo, qk.data_ptr(), out.data_ptr(),
+                                     out.stride(0), out.stride(1), k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
+def memory_read_indices(keys, qk, top_k):
+    """Test/debug: the selected memory indices [K, n_q, k] (best first) and softmax weights."""
+    _ensure_device(keys)
+    keys, ko = _rows(_f32(keys), 128)
+    k, n_mem, _ = keys.shape
+    n_q = qk.shape[0]
+    idx = torch.empty((k, n_q, top_k), dtype=torch.int32, device=keys.device)
+    wgt = torch.empty((k, n_q, top_k), dtype=torch.float32, device=keys.device)
+    lib = _lib.load()
+    ws = _workspace(lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k), keys.device)
+    check(lib.mivos_memory_read_topk_indices(keys.data_ptr(), ko, qk.contiguous().data_ptr(), idx.data_ptr(), wgt.data_ptr(),
+                                             k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
+    return idx, wgt
+
+
+def attention_align(mk, qk, pos16, neg16):
+    """mk [K, n_pos, 128], qk [n_pos, 128], pos16/neg16 [K, n_pos] -> [K, 2, n_pos]."""
+    _ensure_device(mk)
+    k, n_pos, _ = mk.shape
+    mk, qk, pos16, neg16 = (_f32(t).contiguous() for t in (mk, qk, pos16, neg16))
+    out = torch.empty((k, 2, n_pos), dtype=torch.float32, device=mk.device)
+    check(_lib.load().mivos_attention_align(mk.data_ptr(), qk.data_ptr(), pos16.data_ptr(), neg16.data_ptr(), out.data_ptr(), k, n_pos, _stream()))
+    return out
+
+
+def area_pool16(x):
+    """x [planes, H, W] -> [planes, H/16, W/16]."""
+    _ensure_device(x)
+    x = _f32(x).contiguous()
+    p, h, w = x.shape
+    y = torch.empty((p, h // 16, w // 16), dtype=torch.float32, device=x.device)
+    check(_lib.load().mivos_area_pool16(x.data_ptr(), y.data_ptr(), p, h, w, _stream()))
+    return y
+
+
+def resize_bilinear(x, H, W, act=0, out=None):
+    """x [planes, h, w] -> [planes, H, W], align_corners=False; act=1 applies a sigmoid."""
+    _ensure_device(x)
+    x = _f32(x).contiguous()
+    p, h, w = x.shape
+    if out is None:
+        out = torch.empty((p, H, W), dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and out.numel() == p * H * W
+    check(_lib.load().mivos_resize_bilinear(x.data_ptr(), out.data_ptr(), p, h, w, H, W, act, _stream()))
+    return out
+
+
+def aggregate(prob, keep_bg=False, hard=False, soft_bg=True):
+    """prob [K, ...] -> [K+1, ...] (keep_bg) or [K, ...]; model/aggregate.py semantics."""
+    _ensure_device(prob)
+    prob = _f32(prob).contiguous()
+    k = prob.shape[0]
+    p = prob[0].numel()
+    out = torch.empty((k + 1 if keep_bg else k,) + tuple(prob.shape[1:]), dtype=torch.float32, device=prob.device)
+    fn = _lib.load().mivos_aggregate_wbg if soft_bg else _lib.load().mivos_aggregate_sbg
+    check(fn(prob.data_ptr(), out.data_ptr(), k, p, int(keep_bg), int(hard), _stream()))
+    return out
+
+
+def argmax_u8(prob, out=None):
+    """prob [C, ...] planes (plane stride = prob.stride(0)) -> uint8 [...]."""
+    _ensure_device(prob)
+    c = prob.shape[0]
+    p = prob[0].numel()
+    assert prob[0].is_contiguous()
+    if out is None:
+        out = torch.empty(tuple(prob.shape[1:]), dtype=torch.uint8, device=prob.device)
+    assert out.is_contiguous() and out.numel() == p
+    check(_lib.load().mivos_argmax_u8(_f32(prob).data_ptr(), prob.stride(0) if c > 1 else p, out.data_ptr(), c, p, _stream()))
+    return out
+
+
+def mask_diff(mask, prob):
+    _ensure_device(mask)
+    mask, prob = _f32(mask).contiguous(), _f32(prob).contiguous()
+    pos, neg = torch.empty_like(mask), torch.empty_like(mask)
+    check(_lib.load().mivos_mask_diff(mask.data_ptr(), prob.data_ptr(), pos.data_ptr(), neg.data_ptr(), mask.numel(), _stream()))
+    return pos, neg
+
+
+def sigmoid(x):
+    _ensure_device(x)
+    x = _f32(x).contiguous()
+    y = torch.empty_like(x)
+    check(_lib.load().mivos_sigmoid(x.data_ptr(), y.data_ptr(), x.numel(), _stream()))
+    return y
+
+
+def mask_others(masks):
+    """masks [K, ...] -> others[i] = sum_{j != i} masks[j]."""
+    _ensure_device(masks)
+    masks = _f32(masks).contiguous()
+    out = torch.empty_like(masks)
+    check(_lib.load().mivos_mask_others(masks.data_ptr(), out.data_ptr(), masks.shape[0], masks[0].numel(), _stream()))
+    return out
+
+
+def interleave(planes, n, p, c_out, device):
+    """planes: list of (tensor_or_float, batch_stride) per channel (missing channels up to c_out are
+    zero) -> dense NHWC [n, p, c_out].  A float entry is a constant plane."""
+    d = InterleaveDesc()
+    d.C = c_out
+    keep = []
+    for c in range(16):
+        d.plane[c], d.nstride[c], d.cval[c] = None, 0, 0.0
+    for c, (src, ns) in enumerate(planes):
+        if isinstance(src, (int, float)):
+            d.cval[c] = float(src)
+        else:
+            _ensure_device(src)
+            assert src.dtype == torch.float32
+            keep.append(src)
+            d.plane[c], d.nstride[c] = src.data_ptr(), ns
+    out = torch.empty((n, p, c_out), dtype=torch.float32, device=device)
+    check(_lib.load().mivos_interleave_planes(C.byref(d), out.data_ptr(), n, p, _stream()))
+    return out

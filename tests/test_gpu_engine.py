@@ -1,0 +1,129 @@
+"""Network-level and end-to-end parity of the MI355X engine with the CPU oracle and with the golden
+vectors produced by the unmodified reference (needs an MI355X).  Tolerances are the north star's:
+mask IoU >= 0.999 vs the reference path, logits within 1e-3."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mivos_amd.inference_core import InferenceCore
+from mivos_amd.model.aggregate import aggregate_wbg
+from mivos_amd.model.fusion_net import FusionNet
+from mivos_amd.model.propagation.prop_net import PropagationNetwork
+from mivos_amd.util.tensor_util import compute_np_iou
+from oracle import stm_oracle as O
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda:0"
+LOGIT_TOL = 1e-3
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def nets(synthetic_states):
+    sd, fsd = synthetic_states
+    prop, fuse = PropagationNetwork(top_k=20), FusionNet()
+    prop.load_state_dict(sd)
+    fuse.load_state_dict(fsd)
+    return prop.to(DEV).eval(), fuse.to(DEV).eval()
+
+
+@pytest.fixture(scope="module")
+def ops_golden(golden_dir):
+    with np.load(os.path.join(golden_dir, "ops_small.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def mean_iou(a, b, k):
+    return float(np.mean([compute_np_iou(a == j, b == j) for j in range(1, k + 1)]))
+
+
+def test_query_encoder_and_memorize_golden(nets, ops_golden):
+    prop, _ = nets
+    g = ops_golden
+    q = prop.get_query_values(T(g["en_frame"]).to(DEV))
+    for got, name in zip(q, ("en_f16", "en_f8", "en_f4", "en_qk", "en_qv")):
+        ref = T(g[name])
+        assert got.shape == ref.shape
+        assert float((got.cpu() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())), name
+    k, v = prop.memorize(T(g["en_frame"]).to(DEV), T(g["en_masks"]).to(DEV))
+    assert k.shape == g["en_mk"].shape and v.shape == g["en_mv"].shape
+    assert float((k.cpu() - T(g["en_mk"])).abs().max()) < 2e-4
+    assert float((v.cpu() - T(g["en_mv"])).abs().max()) < 2e-4
+
+
+def test_fusion_net_golden(nets, ops_golden):
+    _, fuse = nets
+    g = ops_golden
+    out = fuse(*(T(g[k]).to(DEV) for k in ("fu_im", "fu_s1", "fu_s2", "fu_at", "fu_tm")))
+    assert out.shape == g["fu_out"].shape
+    assert float((out.cpu() - T(g["fu_out"])).abs().max()) < LOGIT_TOL
+
+
+def test_segment_with_query_public_api_vs_oracle(nets, synthetic_states):
+    """Reference-style call sequence on NCHW tensors (what generation/fusion_generator.py does)."""
+    prop, _ = nets
+    sd = synthetic_states[0]
+    images, gt = O.synthetic_clip(3, 128, 160, 2, seed=5)
+    f0, f1 = images[:, 0], images[:, 1]
+    k0, v0 = prop.memorize(f0.to(DEV), gt[0, 1:].to(DEV))
+    q = prop.get_query_values(f1.to(DEV))
+    prob = prop.segment_with_query(k0, v0, *q)
+    ok, ov = O.memorize(sd, f0, gt[0, 1:])
+    oq = O.get_query_values(sd, f1)
+    ref_logit = O.segment_logits(sd, ok, ov, *oq, top_k=20)
+    assert prob.shape == (2, 1, 128, 160)
+    assert float((prob.cpu() - torch.sigmoid(ref_logit)).abs().max()) < 2.5e-4     # d sigmoid <= dlogit / 4
+    kr = k0.permute(0, 2, 3, 4, 1).reshape(2, -1, 128)
+    vr = v0.permute(0, 2, 3, 4, 1).reshape(2, -1, 512)
+    from mivos_amd.model.propagation.prop_net import QueryFeatures, _nhwc
+    logit = prop.segment(kr, vr, QueryFeatures(*(_nhwc(t) for t in q)), logits=True)
+    assert float((logit.cpu().unsqueeze(1) - ref_logit).abs().max()) < LOGIT_TOL
+    out = aggregate_wbg(prob, keep_bg=True)
+    assert float((out.cpu() - O.aggregate_wbg(torch.sigmoid(ref_logit), keep_bg=True)).abs().max()) < 2.5e-4
+
+
+def test_end_to_end_golden(nets, golden_dir):
+    """Same 3-interaction session (incl. fusion) the unmodified reference ran to produce e2e_small.npz."""
+    prop, fuse = nets
+    with np.load(os.path.join(golden_dir, "e2e_small.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    c = json.loads(str(g["config"]))
+    images, gt = O.synthetic_clip(c["t"], c["h"], c["w"], c["k"], c["seed"])
+    core = InferenceCore(prop, fuse, images, c["k"], mem_freq=c["mem_freq"], device=DEV)
+    for n, idx in enumerate(c["interactions"]):
+        out = core.interact(gt[idx], idx)
+        ref = g[f"masks_{n}"]
+        assert out.shape == ref.shape and out.dtype == np.uint8
+        iou = mean_iou(out, ref, c["k"])
+        dprob = float((core.prob.cpu() - T(g[f"prob_{n}"])).abs().max())
+        print(f"interaction {n}: IoU {iou:.6f}  max|dprob| {dprob:.2e}  mismatching px {int((out != ref).sum())}")
+        assert iou >= 0.999
+        assert dprob < 2e-3
+    assert core.propagated_frames == 6 + 5 + 4
+    # update_mask_only keeps its contract
+    m = core.update_mask_only(core.prob[:, 2], 2)
+    assert m.shape == (c["t"], c["h"], c["w"])
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_480p_propagation_vs_oracle(nets, synthetic_states, K):
+    """BASELINE config 2/3 geometry (480x854 -> 480x864, HW = 1620): a short clip against the oracle run on
+    this box's host cores; logits within 1e-3, IoU >= 0.999."""
+    prop, fuse = nets
+    sd, fsd = synthetic_states
+    images, gt = O.synthetic_clip(4, 480, 854, K, seed=20 + K)
+    core = InferenceCore(prop, fuse, images, K, mem_freq=2, device=DEV)
+    ocore = O.OracleCore(sd, fsd, images, K, mem_freq=2, top_k=20)
+    out, ref = core.interact(gt[0], 0), ocore.interact(gt[0], 0)
+    assert mean_iou(out, ref, K) >= 0.999
+    assert float((core.prob.cpu() - ocore.prob).abs().max()) < 5e-4
+    out, ref = core.interact(gt[3], 3), ocore.interact(gt[3], 3)     # fused frames 1, 2
+    assert mean_iou(out, ref, K) >= 0.999
+    assert float((core.prob.cpu() - ocore.prob).abs().max()) < 5e-4

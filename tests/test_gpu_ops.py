@@ -1,0 +1,249 @@
+"""Parity of every HIP kernel family with the CPU oracle / plain torch fp32 (needs an MI355X).
+All calls go through the C ABI (mivos_amd.ops -> libmivos_hip.so)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mivos_amd import ops
+from mivos_amd.ops import ConvLayer
+from oracle import stm_oracle as O
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda:0"
+
+
+def rel_err(got, ref):
+    return float((got.double() - ref.double()).abs().max() / (ref.double().abs().max() + 1e-30))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+CONV_CASES = [
+    # n, cin, cout, k, stride, pad, h, w, relu_in, relu_out, res, bn
+    (1, 64, 64, 1, 1, 0, 30, 54, False, True, False, True),
+    (2, 64, 256, 1, 1, 0, 17, 23, False, True, True, True),       # ragged M, residual
+    (1, 256, 128, 1, 2, 0, 30, 54, False, False, False, True),    # strided 1x1 (downsample)
+    (1, 128, 128, 3, 2, 1, 31, 37, False, True, False, True),     # 3x3 stride 2, odd size
+    (3, 64, 64, 3, 1, 1, 20, 28, True, False, True, False),       # pre-activation, residual
+    (1, 1024, 640, 3, 1, 1, 8, 10, False, False, False, False),   # KeyValue-like, K = 9216
+    (1, 4, 64, 7, 2, 3, 64, 96, False, True, False, True),        # stem (3->4 padded)
+    (2, 8, 64, 7, 2, 3, 48, 80, False, True, False, True),        # mask stem (5->8 padded)
+    (1, 16, 32, 3, 1, 1, 48, 64, False, True, False, False),      # FusionNet conv1 (9->16 padded)
+    (2, 32, 32, 3, 1, 1, 33, 47, False, True, True, False),       # FusionNet residual conv
+    (2, 32, 1, 3, 1, 1, 33, 47, False, False, False, False),      # FusionNet head (Cout = 1)
+    (2, 256, 1, 3, 1, 1, 30, 54, True, False, False, False),      # decoder.pred (Cout = 1, relu_in)
+    (5, 256, 256, 3, 1, 1, 120, 216, True, False, True, False),   # largest decoder shape (128x128 tile path)
+    (1, 512, 200, 3, 1, 1, 9, 11, False, False, False, False),    # Cout not a multiple of the tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c[:8])))
+def test_conv2d_fused(case):
+    n, cin, cout, k, stride, pad, h, w, relu_in, relu_out, use_res, use_bn = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    bn = None
+    if use_bn:
+        bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
+              torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+    xin = F.relu(x) if relu_in else x
+    ref = F.conv2d(xin.double(), wt.double(), b.double(), stride=stride, padding=pad)
+    if bn is not None:
+        ref = F.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0., 1e-5)
+    res = None
+    if use_res:
+        res = torch.randn(n, cout, ref.shape[2], ref.shape[3], generator=g)
+        ref = ref + res.double()
+    if relu_out:
+        ref = F.relu(ref)
+    L = ConvLayer.pack(wt, b, bn, stride, pad).to(DEV)
+    got = ops.conv(nhwc(x).to(DEV), L, relu_in=relu_in, relu_out=relu_out, res=None if res is None else nhwc(res).to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(got.cpu().permute(0, 3, 1, 2), ref) < 2e-6
+
+
+def test_conv2d_strided_views_split_and_broadcast_residual():
+    g = torch.Generator().manual_seed(5)
+    n, cin, h, w = 3, 64, 12, 14
+    big = torch.randn(n, h, w, 160, generator=g).to(DEV)                  # input is a channel slice
+    x = big[..., 32:96]
+    wt = torch.randn(96, cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(96, generator=g) * 0.1
+    res = torch.randn(1, 96, h, w, generator=g)                            # batch-1 residual, broadcast
+    L = ConvLayer.pack(wt, b, None, 1, 1)
+    L.split = 32
+    L = L.to(DEV)
+    bank_a = torch.zeros(n, 4, h, w, 32, device=DEV)                        # destination = slot 2 of a bank
+    bank_b = torch.zeros(n, h, w, 100, device=DEV)                          # destination = channel slice
+    ops.conv(x, L, res=nhwc(res).to(DEV), out=bank_a[:, 2], out2=bank_b[..., 10:74])
+    ref = F.conv2d(x.cpu().permute(0, 3, 1, 2).double(), wt.double(), b.double(), padding=1) + res.double()
+    got = torch.cat([bank_a[:, 2], bank_b[..., 10:74]], -1).cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < 2e-6
+    assert float(bank_a[:, [0, 1, 3]].abs().max()) == 0 and float(bank_b[..., :10].abs().max()) == 0 and float(bank_b[..., 74:].abs().max()) == 0
+
+
+def test_conv_rejects_bad_arguments():
+    L = ConvLayer.pack(torch.randn(8, 12, 3, 3), None, None, 1, 1).to(DEV)
+    with pytest.raises(ops.MivosHipError):
+        ops.conv(torch.zeros(1, 8, 8, 12, device=DEV), L)                   # Cin not a power of two
+    with pytest.raises(ops.MivosHipError):
+        ops.conv(torch.zeros(1, 8, 8, 16), ConvLayer.pack(torch.randn(8, 16, 3, 3), None, None, 1, 1))  # CPU tensor
+
+
+def test_maxpool_and_upsample_add():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 64, 37, 45, generator=g)
+    got = ops.maxpool3x3s2(nhwc(x).to(DEV)).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(got, F.max_pool2d(x, 3, 2, 1))
+    up, skip = torch.randn(3, 32, 15, 27, generator=g), torch.randn(1, 32, 30, 54, generator=g)
+    ref = skip + F.interpolate(up, scale_factor=2, mode="bilinear", align_corners=False)
+    got = ops.upsample2x_add(nhwc(skip).to(DEV), nhwc(up).to(DEV)).cpu().permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max()) < 1e-5
+
+
+def test_resize_area_sigmoid():
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 30, 54, generator=g)
+    for H, W in ((120, 216), (480, 864)):
+        ref = F.interpolate(x[None], size=(H, W), mode="bilinear", align_corners=False)[0]
+        assert float((ops.resize_bilinear(x.to(DEV), H, W).cpu() - ref).abs().max()) < 1e-5
+    ref = torch.sigmoid(F.interpolate(x[None], scale_factor=4, mode="bilinear", align_corners=False)[0])
+    assert float((ops.resize_bilinear(x.to(DEV), 120, 216, act=1).cpu() - ref).abs().max()) < 1e-6
+    m = torch.rand(4, 64, 96, generator=g)
+    ref = F.interpolate(m[None], size=(4, 6), mode="area")[0]
+    assert float((ops.area_pool16(m.to(DEV)).cpu() - ref).abs().max()) < 1e-6
+    assert float((ops.sigmoid(x.to(DEV)).cpu() - torch.sigmoid(x)).abs().max()) < 1e-6
+
+
+def test_aggregate_argmax_diff_others(golden_dir):
+    with np.load(os.path.join(golden_dir, "ops_small.npz")) as z:
+        p, soft, hard, sbg = (torch.from_numpy(z[k]) for k in ("ag_in", "ag_soft", "ag_hard", "ag_sbg"))
+    pd = p.to(DEV)
+    assert float((ops.aggregate(pd, keep_bg=True).cpu() - soft).abs().max()) < 2e-6
+    assert float((ops.aggregate(pd, keep_bg=True, hard=True).cpu() - hard).abs().max()) < 2e-6
+    assert float((ops.aggregate(pd, keep_bg=True, soft_bg=False).cpu() - sbg).abs().max()) < 2e-6
+    assert float((ops.aggregate(pd, keep_bg=False).cpu() - soft[1:]).abs().max()) < 2e-6
+    g = torch.Generator().manual_seed(3)
+    prob = torch.rand(4, 7, 1, 16, 24, generator=g)
+    prob[2, 3] = prob[1, 3]                                   # ties: first index must win
+    got = ops.argmax_u8(prob.to(DEV).view(4, -1)).cpu().view(7, 1, 16, 24)
+    assert torch.equal(got.long(), torch.argmax(prob, dim=0))
+    mask, old = (torch.rand(3, 1, 16, 24, generator=g) > 0.5).float(), torch.rand(3, 1, 16, 24, generator=g)
+    pos, neg = ops.mask_diff(mask.to(DEV), old.to(DEV))
+    assert torch.equal(pos.cpu(), (mask - old).clamp(0, 1)) and torch.equal(neg.cpu(), (old - mask).clamp(0, 1))
+    masks = torch.rand(4, 1, 8, 12, generator=g)
+    ref = torch.cat([masks[[j for j in range(4) if j != i]].sum(0, keepdim=True) for i in range(4)], 0)
+    assert float((ops.mask_others(masks.to(DEV)).cpu() - ref).abs().max()) < 1e-6
+
+
+def test_interleave():
+    g = torch.Generator().manual_seed(4)
+    frame, masks = torch.randn(1, 3, 8, 12, generator=g).to(DEV), torch.rand(2, 1, 8, 12, generator=g).to(DEV)
+    P = 96
+    out = ops.interleave([(frame[0, c], 0) for c in range(3)] + [(masks, P), (0.25, 0)], 2, P, 8, frame.device)
+    ref = torch.cat([frame.expand(2, -1, -1, -1), masks, torch.full_like(masks, 0.25), torch.zeros(2, 3, 8, 12, device=DEV)], 1)
+    assert torch.equal(out.view(2, 8, 12, 8).permute(0, 3, 1, 2), ref)
+
+
+# ------------------------------------------------------------------ memory read
+
+def _mem_case(T, h, w, K, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    mk = torch.randn(K, 128, T, h, w, generator=g) * scale
+    mv = torch.randn(K, 512, T, h, w, generator=g)
+    qk = torch.randn(1, 128, h, w, generator=g) * scale
+    return mk, mv, qk
+
+
+def _run_mem(mk, mv, qk, top_k):
+    K, _, T, h, w = mk.shape
+    keys = mk.permute(0, 2, 3, 4, 1).reshape(K, T * h * w, 128).contiguous().to(DEV)
+    vals = mv.permute(0, 2, 3, 4, 1).reshape(K, T * h * w, 512).contiguous().to(DEV)
+    q = qk.permute(0, 2, 3, 1).reshape(h * w, 128).contiguous().to(DEV)
+    out = ops.memory_read(keys, vals, q, top_k)
+    idx, wgt = ops.memory_read_indices(keys, q, top_k)
+    return out.cpu().view(K, h, w, 512).permute(0, 3, 1, 2), idx.cpu(), wgt.cpu()
+
+
+def test_memory_read_golden(golden_dir):
+    with np.load(os.path.join(golden_dir, "ops_small.npz")) as z:
+        mk, mv, qk, ref = (torch.from_numpy(z[k]) for k in ("mr_mk", "mr_mv", "mr_qk", "mr_out"))
+    got, _, _ = _run_mem(mk, mv, qk, 20)
+    assert float((got - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("T,h,w,K,top_k", [(1, 8, 10, 1, 50), (3, 9, 13, 2, 50), (5, 30, 54, 1, 20), (5, 30, 54, 3, 50), (23, 30, 54, 1, 50)])
+def test_memory_read_vs_oracle(T, h, w, K, top_k):
+    mk, mv, qk = _mem_case(T, h, w, K, seed=T * 100 + K)
+    got, idx, wgt = _run_mem(mk, mv, qk, top_k)
+    for o in range(K):
+        ref = O.memory_read(mk[o:o + 1], mv[o:o + 1], qk, top_k)
+        assert float((got[o:o + 1] - ref).abs().max()) < 2e-4
+        # exact top-k membership: compare index sets where the k-th / (k+1)-th scores are not a near tie
+        a = O.affinity(mk[o:o + 1], qk)[0]                      # [THW, HW]
+        vals, ridx = torch.topk(a, top_k + 1, dim=0)
+        clear = (vals[top_k - 1] - vals[top_k]) > 1e-5
+        got_sets = torch.sort(idx[o].long(), dim=1)[0]          # [HW, k]
+        ref_sets = torch.sort(ridx[:top_k].t(), dim=1)[0]
+        same = (got_sets == ref_sets).all(dim=1)
+        assert bool(same[clear].all()) and float(clear.float().mean()) > 0.99
+        assert torch.equal(idx[o][:, 0].long()[clear], ridx[0][clear])          # best first
+        assert float((wgt[o].sum(1) - 1).abs().max()) < 1e-5
+
+
+def test_memory_read_sharp_scores_and_ties():
+    # large-magnitude keys (softmax nearly one-hot) and duplicated memory rows (exact score ties)
+    mk, mv, qk = _mem_case(2, 8, 10, 1, seed=9, scale=6.0)
+    mk[:, :, 1] = mk[:, :, 0]                                   # frame 1 duplicates frame 0: every score ties
+    got, idx, _ = _run_mem(mk, mv, qk, 20)
+    mv2 = mv.clone()
+    ref = O.memory_read(mk, mv2, qk, 20)
+    # with exact ties torch.topk's choice is unspecified: compare through tie-invariant values
+    mv_t = mv.clone()
+    mv_t[:, :, 1] = mv_t[:, :, 0]
+    got_t, _, _ = _run_mem(mk, mv_t, qk, 20)
+    ref_t = O.memory_read(mk, mv_t, qk, 20)
+    assert float((got_t - ref_t).abs().max()) < 2e-4
+    assert int((idx[0] >= 160).sum()) == 0 or True            # indices stay in range
+    assert int(idx.max()) < 160 and int(idx.min()) >= 0
+
+
+def test_memory_read_topk_out_of_range_raises():
+    mk, mv, qk = _mem_case(1, 4, 6, 1, seed=1)                  # 24 positions < top_k = 50
+    with pytest.raises(RuntimeError, match="out of range"):
+        _run_mem(mk, mv, qk, 50)
+
+
+def test_memory_read_writes_into_channel_slice():
+    mk, mv, qk = _mem_case(2, 8, 10, 2, seed=11)
+    keys = mk.permute(0, 2, 3, 4, 1).reshape(2, 160, 128).contiguous().to(DEV)
+    vals = mv.permute(0, 2, 3, 4, 1).reshape(2, 160, 512).contiguous().to(DEV)
+    q = qk.permute(0, 2, 3, 1).reshape(80, 128).contiguous().to(DEV)
+    m4 = torch.full((2, 80, 1024), 7.0, device=DEV)
+    ops.memory_read(keys, vals, q, 20, out=m4[:, :, :512])
+    dense = ops.memory_read(keys, vals, q, 20)
+    assert torch.equal(m4[:, :, :512], dense) and float((m4[:, :, 512:] - 7).abs().max()) == 0
+
+
+def test_attention_align(golden_dir):
+    with np.load(os.path.join(golden_dir, "ops_small.npz")) as z:
+        mk, qk, pos, neg, ref = (torch.from_numpy(z[k]) for k in ("at_mk", "at_qk", "at_pos", "at_neg", "at_out"))
+    from mivos_amd.model.propagation.prop_net import PropagationNetwork
+    net = PropagationNetwork()
+    got = net.get_attention(mk.to(DEV), pos.to(DEV), neg.to(DEV), qk.to(DEV)).cpu()
+    assert float((got - ref).abs().max()) < 1e-5
+    # 480p-sized random case, 3 objects, against the oracle
+    g = torch.Generator().manual_seed(12)
+    mk, qk = torch.randn(3, 128, 1, 30, 54, generator=g), torch.randn(1, 128, 30, 54, generator=g)
+    pos, neg = torch.rand(3, 1, 480, 864, generator=g), torch.rand(3, 1, 480, 864, generator=g)
+    got = net.get_attention(mk.to(DEV), pos.to(DEV), neg.to(DEV), qk.to(DEV)).cpu()
+    ref = torch.cat([O.get_attention(mk[i:i + 1], pos[i:i + 1], neg[i:i + 1], qk) for i in range(3)], 0)
+    assert float((got - ref).abs().max()) < 1e-5

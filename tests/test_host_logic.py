@@ -1,0 +1,140 @@
+"""CPU-only checks of the host side: schedule planner vs the reference's golden trace, state_dict
+compatibility, BN folding / weight packing, C-ABI symbol export, loud failure without a GPU."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mivos_amd import _lib
+from mivos_amd.inference_core import InferenceCore, plan_pass
+from mivos_amd.model.fusion_net import FusionNet
+from mivos_amd.model.propagation.prop_net import PropagationNetwork
+from mivos_amd.ops import ConvLayer
+from mivos_amd.util.tensor_util import pad_divide_by, unpad, compute_np_iou
+
+torch.set_grad_enabled(False)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def simulate_trace(t, k, mem_freq, interactions):
+    """Token stream of InferenceCore.interact in SURVEY.md §3 notation, from plan_pass alone."""
+    trace, interacted, cached, n_certain = [], set(), set(), 0
+    for idx in interactions:
+        interacted.add(idx)
+        trace.append("M")
+        n_certain += 1
+        for fwd in (True, False):
+            closest, total, steps = plan_pass(t, interacted, idx, fwd, mem_freq, n_certain)
+            for st in steps:
+                if st.ti not in cached:
+                    cached.add(st.ti)
+                    trace.append("Q")
+                trace.append(f"S{st.n_read}")
+                assert st.n_read <= total and (st.slot is None or st.slot < total)
+                if st.slot is not None:
+                    trace.append("M")
+                if st.fuse:
+                    nc, nr = abs(closest - st.ti) / abs(closest - idx), abs(idx - st.ti) / abs(closest - idx)
+                    trace += [f"F({nc:.2f},{nr:.2f})"] * k
+    return trace
+
+
+def test_schedule_matches_reference_golden_trace(golden_dir):
+    with np.load(os.path.join(golden_dir, "e2e_small.npz")) as z:
+        c, golden = json.loads(str(z["config"])), str(z["trace"])
+    assert " ".join(simulate_trace(c["t"], c["k"], c["mem_freq"], c["interactions"])) == golden
+
+
+def test_schedule_survey_example():
+    # SURVEY.md §3 golden control-flow trace: T=13, K=2, mem_freq=5, interactions 0, 12, 6
+    tr = " ".join(simulate_trace(13, 2, 5, [0, 12, 6]))
+    first = "M Q S1 M " + "Q S2 M " * 5 + "Q S3 M " * 5 + "Q S4"
+    assert tr.startswith(first)
+    second = tr[len(first) + 1:]
+    assert second.startswith("M S2 M F(0.92,0.08) F(0.92,0.08)")
+    assert "F(0.50,0.50)" in second and tr.count("Q") == 12
+
+
+def test_schedule_edge_cases():
+    # interacting on the last frame: nothing to do forward
+    closest, total, steps = plan_pass(5, {4}, 4, True, 5, 1)
+    assert steps == [] and closest == 5
+    # adjacent interacted frames: no frame in between
+    assert plan_pass(5, {2, 3}, 2, True, 5, 2)[2] == []
+    # mem_freq 1 keeps every frame
+    _, total, steps = plan_pass(6, {0}, 0, True, 1, 1)
+    assert [s.n_read for s in steps] == [1, 2, 3, 4, 5] and total == 7   # (5 // 1) + 1 + 1, the reference's bank size formula
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
+    assert {k: list(v.shape) for k, v in PropagationNetwork().state_dict().items()} == keys["prop"]
+    assert {k: list(v.shape) for k, v in FusionNet().state_dict().items()} == keys["fuse"]
+
+
+def test_load_state_dict_strict(synthetic_states):
+    sd, fsd = synthetic_states
+    p, f = PropagationNetwork(top_k=20), FusionNet()
+    p.load_state_dict(sd, strict=True)
+    f.load_state_dict(fsd, strict=True)
+    assert torch.equal(p.decoder.pred.weight, sd["decoder.pred.weight"])
+
+
+def test_pack_folds_batchnorm(synthetic_states):
+    """ConvLayer.pack: conv*scale + bias == BN(conv + b) of the oracle, OHWI weights, channel padding."""
+    sd = synthetic_states[0]
+    p = PropagationNetwork()
+    p.load_state_dict(sd)
+    blk = p.mask_rgb_encoder.layer2[0]
+    L = blk.conv2.pack(blk.bn2)
+    x = torch.randn(1, 128, 10, 12)
+    ref = F.batch_norm(F.conv2d(x, sd["mask_rgb_encoder.layer2.0.conv2.weight"], sd["mask_rgb_encoder.layer2.0.conv2.bias"], stride=2, padding=1),
+                       sd["mask_rgb_encoder.layer2.0.bn2.running_mean"], sd["mask_rgb_encoder.layer2.0.bn2.running_var"],
+                       sd["mask_rgb_encoder.layer2.0.bn2.weight"], sd["mask_rgb_encoder.layer2.0.bn2.bias"], False, 0., 1e-5)
+    w = L.w.permute(0, 3, 1, 2)   # OHWI -> OIHW
+    got = F.conv2d(x, w, None, stride=2, padding=1) * L.scale[None, :, None, None] + L.bias[None, :, None, None]
+    assert float((got - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    stem = p.mask_rgb_encoder.conv1.pack(p.mask_rgb_encoder.bn1, cin_pad=8)
+    assert stem.w.shape == (64, 7, 7, 8) and float(stem.w[..., 5:].abs().max()) == 0.0
+    kv = p.kv_m_f16.compile()
+    assert kv.cout == 640 and kv.split == 128 and kv.w.shape == (640, 3, 3, 1024)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libmivos_hip.so loads and exports every function include/mivos_hip.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "mivos_hip.h")).read()
+    declared = set(re.findall(r"\b(mivos_[a-z0-9_]+)\s*\(", hdr)) - {"mivos_status"}
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().mivos_version() == 1
+
+
+def test_cpu_tensors_fail_loudly(synthetic_states):
+    """No CPU fallback: the product path refuses to run without an MI355X."""
+    p = PropagationNetwork()
+    with pytest.raises(_lib.MivosHipError):
+        p.get_query_values(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(_lib.MivosHipError):
+        FusionNet()(torch.zeros(1, 3, 16, 16), torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 16, 16), torch.zeros(1, 2, 16, 16), torch.zeros(1, 2))
+    with pytest.raises(_lib.MivosHipError):
+        InferenceCore(p, FusionNet(), torch.zeros(1, 2, 3, 32, 32), 1, device="cpu")
+
+
+def test_tensor_util_matches_oracle():
+    from oracle import stm_oracle as O
+    for shape in [(1, 3, 480, 854), (2, 1, 120, 150), (1, 1, 101, 35), (1, 1, 64, 64)]:
+        x = torch.randn(*shape)
+        a, pa = pad_divide_by(x, 16)
+        b, pb = O.pad_divide_by(x, 16)
+        assert pa == pb and torch.equal(a, b)
+        assert torch.equal(unpad(a, pa), x)
+    s, g = np.zeros((4, 4), bool), np.zeros((4, 4), bool)
+    s[:2], g[1:3] = True, True
+    assert abs(float(compute_np_iou(s, g)) - 1 / 3) < 1e-5
