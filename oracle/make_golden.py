@@ -106,7 +106,26 @@ def main():
     np.savez_compressed(os.path.join(G, "ops_small.npz"), **ops)
 
     # 4. end-to-end with the reference InferenceCore ----------------------------------
-    c = E2E
+    # pick the clip whose top-k selections have the widest margin and where the fp32 and fp64
+    # runs of the algorithm agree: an end-to-end fixture must not hinge on rounding-level ties
+    c = dict(E2E)
+    best = None
+    for seed in range(3, 11):
+        images, gt = O.synthetic_clip(c["t"], c["h"], c["w"], c["k"], seed)
+        O.TOPK_GAP = []
+        a = O.OracleCore(sd, fsd, images, c["k"], mem_freq=c["mem_freq"], top_k=c["top_k"])
+        b = O.OracleCore(sd, fsd, images, c["k"], mem_freq=c["mem_freq"], top_k=c["top_k"], dtype=torch.float64)
+        for idx in c["interactions"]:
+            ma, mb = a.interact(gt[idx], idx), b.interact(gt[idx], idx)
+        gap = min(O.TOPK_GAP)
+        O.TOPK_GAP = None
+        dp = float((a.prob.double() - b.prob).abs().max())
+        print(f"seed {seed}: min top-k margin {gap:.2e}, fp32-vs-fp64 |dprob| {dp:.2e}, mask mismatch {int((ma != mb).sum())}")
+        score = (dp < 2e-4, gap)
+        if best is None or score > best[0]:
+            best = (score, seed)
+    c["seed"] = best[1]
+    print("chosen seed", c["seed"])
     images, gt = O.synthetic_clip(c["t"], c["h"], c["w"], c["k"], c["seed"])
     trace = []
 

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 # ------------------------------------------------------------------ primitive layers
 
+TOPK_GAP = None  # set to a list to record top-k selection margins (see topk_softmax)
 _CALIB = None   # when set (dict), BN measures + stores statistics (oracle/weights.calibrate)
 
 
@@ -149,6 +150,11 @@ def topk_softmax(aff, top_k):
     (segment_with_query batched=1, prop_net.py:173-176)."""
     assert aff.shape[0] == 1
     values, indices = torch.topk(aff, k=top_k, dim=1)
+    if TOPK_GAP is not None and aff.shape[1] > top_k:
+        # conditioning probe (make_golden.py): smallest margin between the k-th and (k+1)-th score;
+        # a margin at rounding level means top-k membership is decided by fp32 noise
+        v2 = torch.topk(aff, k=top_k + 1, dim=1)[0]
+        TOPK_GAP.append(float((v2[:, top_k - 1] - v2[:, top_k]).min()))
     e = torch.exp(values - values[:, 0])
     e = e / e.sum(dim=1, keepdim=True)
     return torch.zeros_like(aff).scatter_(1, indices, e), values, indices

@@ -67,7 +67,7 @@ def test_conv2d_fused(case):
     L = ConvLayer.pack(wt, b, bn, stride, pad).to(DEV)
     got = ops.conv(nhwc(x).to(DEV), L, relu_in=relu_in, relu_out=relu_out, res=None if res is None else nhwc(res).to(DEV))
     torch.cuda.synchronize()
-    assert rel_err(got.cpu().permute(0, 3, 1, 2), ref) < 2e-6
+    assert rel_err(got.cpu().permute(0, 3, 1, 2), ref) < max(2e-6, 6e-8 * (cin * k * k) ** 0.5)   # fp32 chain over K terms
 
 
 def test_conv2d_strided_views_split_and_broadcast_residual():
