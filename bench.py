@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X propagation + fusion engine (BASELINE.json metric: propagated frames/sec,
+DAVIS-2017 480p multi-object).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--objects 5] [--height 480 --width 854]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one propagated frame = one iteration of the reference's do_pass loop
+(`inference_core.py:165`): query features (cached per frame), per-object top-k memory read, mask decoder,
+aggregation, memorize into the bank, and — on the second interaction — difference-aware fusion.
+Workload (BASELINE config 3): one synthetic 480x854 clip per GPU, K objects, top_k=50, mem_freq=5;
+`interact(mask, 0)` propagates T-1 frames, `interact(mask, T-1)` re-propagates T-2 frames with fusion.
+T is sized so that the session has >= warmup + steps propagated frames; the timed region is exactly
+`steps` of them, bracketed by barrier + torch.cuda.synchronize().  All inputs are resident in HBM
+before the timed region (mem_profile 0).  Multi-GPU: sequences shard (one clip per rank, no data-path
+collective), value = frames of all ranks / max-over-ranks time, scaling = weak.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+VARIANT_NAMES = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<64,64,2,2>",
+                 2: "conv_igemm_kernel<128,32,4,1>", 3: "conv_igemm_kernel<128,64,2,2>", 4: "conv_cout1_kernel"}
+
+
+class StepTimer:
+    """step_cb hook: synchronises + stamps the clock exactly at step `warmup` and `warmup + steps`."""
+
+    def __init__(self, warmup, steps, profile_every, ops, shard):
+        self.warmup, self.steps, self.every, self.ops, self.shard = warmup, steps, profile_every, ops, shard
+        self.n, self.t0, self.t1, self.samples = 0, None, None, []
+        self._arm()
+
+    def _arm(self):
+        if self.n == self.warmup and self.t0 is None:
+            torch.cuda.synchronize()
+            self.shard.barrier()
+            torch.cuda.synchronize()
+            self.t0 = time.perf_counter()
+        timed = self.t0 is not None and self.t1 is None
+        # sample every `every`-th timed step with HIP events around each conv launch
+        self.ops.PROFILE = self.samples if (timed and self.every and (self.n - self.warmup) % self.every == 0) else None
+
+    def __call__(self):
+        self.n += 1
+        if self.n == self.warmup + self.steps and self.t1 is None:
+            torch.cuda.synchronize()
+            self.shard.barrier()
+            torch.cuda.synchronize()
+            self.t1 = time.perf_counter()
+        self._arm()
+
+
+def conv_roofline(samples):
+    """Aggregate the HIP-event samples per kernel instantiation; the dominant one is the roofline kernel."""
+    agg = {}
+    for variant, flops, e0, e1 in samples:
+        a = agg.setdefault(variant, [0.0, 0.0, 0])
+        a[0] += flops
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += 1
+    if not agg:
+        return None, {}
+    table = {VARIANT_NAMES[v]: dict(launches=a[2], avg_us=round(a[1] / a[2] * 1e6, 2), tflops=round(a[0] / a[1] / 1e12, 2),
+                                    time_share=round(a[1] / sum(x[1] for x in agg.values()), 3)) for v, a in sorted(agg.items())}
+    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    v, (flops, secs, n) = dom
+    ach = flops / secs / 1e12
+    roof = dict(bound="mfma", kernel=VARIANT_NAMES[v], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, launches_sampled=n,
+                avg_launch_us=round(secs / n * 1e6, 2), algorithmic_gflop_per_launch=round(flops / n / 1e9, 3))
+    return roof, table
+
+
+def cpu_baseline(images, gt, k, top_k, mem_freq, engine_masks, frames):
+    """The CPU oracle (restatement of the reference, oracle/stm_oracle.py) on a bounded sample of the same
+    workload: the first `frames` propagated frames of the first interaction."""
+    from oracle import stm_oracle as O
+    from mivos_amd.util import synthetic
+    from mivos_amd.util.tensor_util import compute_np_iou
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd, fsd = synthetic.make_prop_state(0), synthetic.make_fuse_state(0)
+    core = O.OracleCore(sd, fsd, images[:, :frames + 1], k, mem_freq=mem_freq, top_k=top_k)
+    t0 = time.perf_counter()
+    ref = core.interact(gt[0], 0)
+    dt = time.perf_counter() - t0
+    ious = [float(compute_np_iou(engine_masks[1:frames + 1] == j, ref[1:] == j)) for j in range(1, k + 1)]
+    return dict(value=round(frames / dt, 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"first {frames} propagated frames of the same clip ({k} objects, no fusion), oracle/stm_oracle.py on PyTorch-CPU fp32",
+                seconds=round(dt, 2)), dict(mean_iou_vs_oracle=round(sum(ious) / len(ious), 6), frames=frames)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--objects", type=int, default=5)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=854)
+    ap.add_argument("--top-k", type=int, default=50)
+    ap.add_argument("--mem-freq", type=int, default=5)
+    ap.add_argument("--cpu-frames", type=int, default=3, help="propagated frames of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--profile-every", type=int, default=8, help="HIP-event sample every n-th timed step (0 = off)")
+    args = ap.parse_args()
+
+    torch.set_grad_enabled(False)
+    from mivos_amd import ops, shard
+    from mivos_amd.inference_core import InferenceCore
+    from mivos_amd.model.fusion_net import FusionNet
+    from mivos_amd.model.propagation.prop_net import PropagationNetwork
+    from mivos_amd.util import synthetic
+
+    rank, world, local = shard.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+
+    K, need = args.objects, args.warmup + args.steps
+    T = max(4, (need + 3 + 1) // 2)                       # session has 2T-3 propagated frames
+    prop, fuse = PropagationNetwork(top_k=args.top_k), FusionNet()
+    prop.load_state_dict(synthetic.make_prop_state(0))
+    fuse.load_state_dict(synthetic.make_fuse_state(0))
+    images, gt = synthetic.synthetic_clip(T, args.height, args.width, K, seed=100 + rank)
+    core = InferenceCore(prop.eval(), fuse.eval(), images, K, mem_profile=0, mem_freq=args.mem_freq, device=dev)
+
+    timer = StepTimer(args.warmup, args.steps, args.profile_every, ops, shard)
+    masks_first = core.interact(gt[0], 0, step_cb=timer).copy()
+    core.interact(gt[T - 1], T - 1, step_cb=timer)
+    ops.PROFILE = None
+    torch.cuda.synchronize()
+    assert timer.t0 is not None and timer.t1 is not None and core.propagated_frames >= need, (core.propagated_frames, need)
+    elapsed = shard.max_over_ranks(timer.t1 - timer.t0, device=dev)
+    recs = shard.gather_records([dict(rank=rank, frames=args.steps, seconds=timer.t1 - timer.t0)])
+
+    if rank != 0:
+        return
+    roof, table = conv_roofline(timer.samples)
+    out = dict(metric="propagated frames/sec, DAVIS-2017 480p multi-object", value=round(world * args.steps / elapsed, 3),
+               unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
+               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload=f"davis480p_multiobject_fusion: {args.height}x{args.width} clip of {T} frames per GPU, "
+                                    f"{K} objects, top_k={args.top_k}, mem_freq={args.mem_freq}, interact(0) then interact({T - 1}) "
+                                    f"(fused re-propagation); timed steps {args.warmup}..{args.warmup + args.steps} of {2 * T - 3}",
+                           objects=K, frames=T, height=args.height, width=args.width, top_k=args.top_k, mem_freq=args.mem_freq,
+                           plain_frames_timed=max(0, min(T - 1, need) - args.warmup), parallelism=f"sequence-sharded x{world}"),
+               roofline=roof, conv_kernels=table, per_rank=recs)
+    if world == 1 and args.cpu_frames > 0:
+        out["cpu_baseline"], out["parity"] = cpu_baseline(images, gt, K, args.top_k, args.mem_freq, masks_first, args.cpu_frames)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,9 @@ typedef struct {
 } mivos_conv_desc;
 
 int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream);
+/* Which kernel instantiation mivos_conv2d_fused picks for M = N*Ho*Wo output pixels and Cout channels
+ * (0: 128x128 tile, 1: 64x64, 2: 128x32, 3: 128x64, 4: Cout==1 dot product) — for profilers/benchmarks. */
+int mivos_conv2d_variant(int M, int Cout);
 
 /* MaxPool2d(3, stride 2, pad 1) on NHWC (mod_resnet.py:121 / torchvision stem). C % 4 == 0. */
 int mivos_maxpool3x3s2(const float *x, float *y, int N, int H, int W, int C, void *stream);

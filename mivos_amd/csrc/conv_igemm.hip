@@ -229,6 +229,15 @@ static int launch_igemm(ConvP &p, hipStream_t st) {
   return check_launch("conv_igemm");
 }
 
+// Tile selection.  0: 128x128 (best MFMA:LDS ratio, needs >= ~1 workgroup per CU), 1: 64x64,
+// 2: 128x32 (Cout <= 32), 3: 128x64 (Cout <= 64, many pixels), 4: Cout == 1 dot-product kernel.
+static int select_variant(int M, int Cout) {
+  if (Cout == 1) return 4;
+  if (Cout <= 32) return 2;
+  if (Cout <= 64) return cdiv(M, 128) >= 200 ? 3 : 1;
+  return (long long)cdiv(M, 128) * cdiv(Cout, 128) >= 200 ? 0 : 1;
+}
+
 }  // namespace mivos
 
 using namespace mivos;
@@ -269,13 +278,12 @@ extern "C" int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream) {
     }
     return check_launch("conv_cout1");
   }
-  // tile selection: the 128x128 tile has the best MFMA:LDS ratio but needs >= ~1 workgroup per CU
-  const long long big = (long long)cdiv(p.M, 128) * cdiv(p.Cout, 128);
-  if (p.Cout <= 32) return launch_igemm<128, 32, 4, 1>(p, st);
-  if (p.Cout <= 64) {
-    if (cdiv(p.M, 128) >= 200) return launch_igemm<128, 64, 2, 2>(p, st);
-    return launch_igemm<64, 64, 2, 2>(p, st);
+  switch (select_variant(p.M, p.Cout)) {
+    case 0: return launch_igemm<128, 128, 2, 2>(p, st);
+    case 1: return launch_igemm<64, 64, 2, 2>(p, st);
+    case 2: return launch_igemm<128, 32, 4, 1>(p, st);
+    default: return launch_igemm<128, 64, 2, 2>(p, st);
   }
-  if (big >= 200) return launch_igemm<128, 128, 2, 2>(p, st);
-  return launch_igemm<64, 64, 2, 2>(p, st);
 }
+
+extern "C" int mivos_conv2d_variant(int M, int Cout) { return select_variant(M, Cout); }

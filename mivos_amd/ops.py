@@ -13,6 +13,9 @@ from . import _lib
 from ._lib import ConvDesc, InterleaveDesc, MivosHipError, check
 
 _checked_devices = set()
+# bench.py sets this to a list to time every conv launch with HIP events on the launch stream:
+# entries (kernel variant, algorithmic FLOPs = 2*M*Cout*KH*KW*Cin, start event, end event)
+PROFILE = None
 
 
 def _ensure_device(t):
@@ -124,7 +127,14 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None):
         d.res = _f32(res).data_ptr()
         rn, rp = _nhwc_strides(res)
         d.res_nstride, d.res_pstride = (0 if (res.shape[0] == 1 and n > 1) else rn), rp
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(_lib.load().mivos_conv2d_fused(C.byref(d), _stream()))
+    if PROFILE is not None:
+        ev1.record()
+        m = n * ho * wo
+        PROFILE.append((_lib.load().mivos_conv2d_variant(m, L.cout), 2.0 * m * L.cout * L.k * L.k * cin, ev0, ev1))
     return (out, out2) if dual else out
 
 

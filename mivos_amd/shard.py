@@ -1,0 +1,69 @@
+"""Sequence sharding across the GPUs of a node (one process per GPU, RCCL over xGMI).
+
+Video sequences are independent units of work (the reference deletes its processor between
+sequences, eval_interactive_davis.py:79-83), so the data path has NO collective: every rank runs
+its own clips on its own replica of the weights.  The only exchange is a latency-bound gather of a
+few hundred bytes of per-clip records at the end (``gather_records``); xGMI bandwidth is irrelevant.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*).
+    backend defaults to 'nccl' (= RCCL on ROCm) when a GPU is visible, else 'gloo'.  Returns
+    (rank, world_size, local_rank); a single-process run returns (0, 1, 0) without initialising."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def clip_cost(n_frames, n_objects):
+    """Relative cost of a clip: every propagated frame costs one object-independent part (query
+    encoder + decoder skip branches) plus a per-object part (memorize + decode), SURVEY.md §8(d)."""
+    return n_frames * (1.0 + 1.6 * n_objects)
+
+
+def assign_sequences(costs, world_size):
+    """Longest-processing-time-first greedy partition.  costs: list of floats.  Returns a list of
+    world_size lists of clip indices; deterministic, identical on every rank."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0.0] * world_size
+    parts = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda j: (loads[j], j))
+        parts[r].append(i)
+        loads[r] += costs[i]
+    return parts
+
+
+def gather_records(records):
+    """All ranks' per-clip records (small picklable objects) on every rank, ordered by rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(records)
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, list(records))
+    return [r for part in out for r in part]
+
+
+def max_over_ranks(value, device=None):
+    """max of a python float over all ranks (the timed-region contract of bench.py)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

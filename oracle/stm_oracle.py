@@ -366,38 +366,4 @@ class OracleCore:
         return self.np_masks
 
 # ------------------------------------------------------------------ synthetic clips
-
-
-def synthetic_clip(t, h, w, k, seed=0):
-    """Band-limited random RGB frames (ImageNet-normalised as dataset/range_transform.py:5-8)
-    and K disjoint moving ellipses.  Returns images [1,T,3,h,w] f32, masks one-hot
-    [T,K+1,1,h,w] f32 (channel 0 = background)."""
-    r = np.random.RandomState(1234 + seed)
-    base = r.standard_normal((3, h // 8 + 2, w // 8 + 2)).astype(np.float32)
-    drift = r.standard_normal((3, h // 8 + 2, w // 8 + 2)).astype(np.float32)
-    mean = np.array([0.485, 0.456, 0.406], np.float32)[:, None, None]
-    std = np.array([0.229, 0.224, 0.225], np.float32)[:, None, None]
-    frames = []
-    for i in range(t):
-        a = i / max(t - 1, 1)
-        lo = torch.from_numpy((1 - a) * base + a * drift)[None]
-        img = F.interpolate(lo, size=(h, w), mode="bicubic", align_corners=False)[0].numpy()
-        img = np.clip(0.5 + 0.22 * img, 0, 1)
-        img = np.round(img * 255) / 255
-        frames.append((img - mean) / std)
-    images = torch.from_numpy(np.stack(frames).astype(np.float32))[None]
-    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
-    masks = np.zeros((t, k + 1, 1, h, w), np.float32)
-    cy0 = r.uniform(0.3, 0.7, k) * h
-    cx0 = (np.arange(k) + 0.5) / k * w
-    vy, vx = r.uniform(-0.15, 0.15, k) * h, r.uniform(-0.08, 0.08, k) * w
-    ry, rx = r.uniform(0.12, 0.25, k) * h, np.full(k, 0.35 / k * w)
-    for i in range(t):
-        a = i / max(t - 1, 1)
-        label = np.zeros((h, w), np.int64)
-        for j in range(k):
-            inside = ((yy - cy0[j] - a * vy[j]) / ry[j]) ** 2 + ((xx - cx0[j] - a * vx[j]) / rx[j]) ** 2 < 1
-            label[inside & (label == 0)] = j + 1
-        for j in range(k + 1):
-            masks[i, j, 0] = label == j
-    return images, torch.from_numpy(masks)
+from mivos_amd.util.synthetic import synthetic_clip  # noqa: E402,F401  (shared input generator)

@@ -1,183 +1,16 @@
-"""Synthetic, seeded weights in the reference's ``state_dict`` layout.
+"""Calibration of the synthetic weights (TEST INFRASTRUCTURE; run once by oracle/make_golden.py).
 
-TEST INFRASTRUCTURE ONLY (used by tests/, bench.py's cpu_baseline leg and
-``__graft_entry__.smoke()``; never by the product path).
-
-The released MiVOS checkpoints are Google-Drive downloads (`download_model.py:8-14`)
-and cannot be fetched here, so every parity test runs on a synthetic weight set that
-is laid out exactly like the reference's ``state_dict`` (597 keys for
-``PropagationNetwork``, 12 for ``FusionNet``; the key/shape tables below restate
-`model/propagation/prop_net.py:131-142`, `modules.py:15-114`, `mod_resnet.py:76-151`,
-torchvision-0.8.2 ``resnet50`` and `model/fusion_net.py:8-30`; they are pinned against
-the real reference by tests/golden/state_dict_keys.json).
-
-Values come from ``numpy.random.RandomState`` (bit-stable across numpy versions),
-one stream per tensor seeded by crc32(name)^seed, so they do not depend on torch's
-RNG, thread count or construction order.  BatchNorm running statistics are NOT drawn
-at random (that is badly conditioned); they are calibrated once by a
-forward pass (``calibrate``) together with LSUV-style gains for the BN-free convs and
-committed as ``tests/golden/calib_{prop,fuse}_seed0.npz`` so that this container and the
-GPU box use identical numbers.
+The weight recipe itself (specs, seeded values, conditioning knobs) lives in
+``mivos_amd/util/synthetic.py`` so that bench.py can build the same networks without touching the
+oracle; everything is re-exported here for the tests.
 """
-import os
-import zlib
 from collections import OrderedDict
 
-import numpy as np
 import torch
 
-GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-
-# ----------------------------------------------------------------------------- specs
-
-def _conv(spec, name, cout, cin, k, bias):
-    spec[name + ".weight"] = (cout, cin, k, k)
-    if bias:
-        spec[name + ".bias"] = (cout,)
-
-
-def _bn(spec, name, c):
-    spec[name + ".weight"] = (c,)
-    spec[name + ".bias"] = (c,)
-    spec[name + ".running_mean"] = (c,)
-    spec[name + ".running_var"] = (c,)
-    spec[name + ".num_batches_tracked"] = ()
-
-
-def _resnet50_to_layer3(spec, prefix, in_ch, bias, layer1_name):
-    """ResNet-50 stem + stages 1..3 (v1.5: stride on the 3x3).  `bias` selects the
-    reference's modified ResNet (`mod_resnet.py:84-89`, plain nn.Conv2d => bias) vs
-    torchvision's (bias-free)."""
-    _conv(spec, prefix + "conv1", 64, in_ch, 7, bias)
-    _bn(spec, prefix + "bn1", 64)
-    cin = 64
-    for lname, width, depth in ((layer1_name, 64, 3), ("layer2", 128, 4), ("layer3", 256, 6)):
-        for b in range(depth):
-            p = f"{prefix}{lname}.{b}."
-            _conv(spec, p + "conv1", width, cin, 1, bias); _bn(spec, p + "bn1", width)
-            _conv(spec, p + "conv2", width, width, 3, bias); _bn(spec, p + "bn2", width)
-            _conv(spec, p + "conv3", width * 4, width, 1, bias); _bn(spec, p + "bn3", width * 4)
-            if b == 0:
-                _conv(spec, p + "downsample.0", width * 4, cin, 1, bias)
-                _bn(spec, p + "downsample.1", width * 4)
-            cin = width * 4
-
-
-def _resblock(spec, p, cin, cout):
-    if cin != cout:
-        _conv(spec, p + "downsample", cout, cin, 3, True)
-    _conv(spec, p + "conv1", cout, cin, 3, True)
-    _conv(spec, p + "conv2", cout, cout, 3, True)
-
-
-def prop_spec():
-    """name -> shape for PropagationNetwork.state_dict() (597 entries)."""
-    s = OrderedDict()
-    _resnet50_to_layer3(s, "mask_rgb_encoder.", 5, True, "layer1")     # modules.py:38-50
-    _resnet50_to_layer3(s, "rgb_encoder.", 3, False, "res2")           # modules.py:67-78
-    for kv in ("kv_m_f16.", "kv_q_f16."):                              # modules.py:107-111
-        _conv(s, kv + "key_proj", 128, 1024, 3, True)
-        _conv(s, kv + "val_proj", 512, 1024, 3, True)
-    _resblock(s, "decoder.compress.", 1024, 512)                       # prop_net.py:14-21
-    for up, skip_c, up_c, out_c in (("decoder.up_16_8.", 512, 512, 256), ("decoder.up_8_4.", 256, 256, 256)):
-        _conv(s, up + "skip_conv1", up_c, skip_c, 3, True)             # modules.py:92-98
-        _resblock(s, up + "skip_conv2.", up_c, up_c)
-        _resblock(s, up + "out_conv.", up_c, out_c)
-    _conv(s, "decoder.pred", 1, 256, 3, True)
-    return s
-
-
-def fuse_spec():
-    """name -> shape for FusionNet.state_dict() (12 entries), fusion_net.py:8-30."""
-    s = OrderedDict()
-    _conv(s, "conv1.0", 32, 9, 3, True)
-    for blk in ("conv2", "conv3"):
-        _conv(s, blk + ".0", 32, 32, 3, True)
-        _conv(s, blk + ".2", 32, 32, 3, True)
-    _conv(s, "final_conv", 1, 32, 3, True)
-    return s
-
-# ----------------------------------------------------------------------------- values
-# Conditioning of the synthetic network (see DESIGN.md "Parity on an untrained network").  The
-# reference algorithm is discontinuous (top-k membership, argmax) and, closed-loop, feeds its own
-# masks back through memorize().  A *trained* STM has sharp affinities (the k-th survivor's softmax
-# weight is ~0, so which of two tied candidates survives is irrelevant) and a stable mask feedback;
-# a raw random network has neither, and then even the reference's own fp32 and fp64 runs disagree.
-# These three knobs give the synthetic weights those two properties:
-MASK_CHANNEL_GAIN = 0.25   # stem weights of the mask / "others" input channels (feedback gain)
-KEY_STD = 3.0              # std of memory / query keys  => affinity std ~ 9 (sharp top-k softmax)
-LOGIT_STD = 1.5            # std of the mask logit       => confident but not saturating in fp32
-
-def _rs(name, seed):
-    return np.random.RandomState((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF)
-
-
-def _draw(name, shape, seed, gain=1.0):
-    leaf = name.rsplit(".", 1)[1]
-    if leaf == "num_batches_tracked":
-        return torch.tensor(1, dtype=torch.int64)
-    r = _rs(name, seed)
-    if leaf == "running_mean":
-        v = np.zeros(shape)
-    elif leaf == "running_var":
-        v = np.ones(shape)
-    elif len(shape) == 4:                                   # conv weight: He / fan-in
-        fan_in = shape[1] * shape[2] * shape[3]
-        v = r.standard_normal(shape) * (gain * np.sqrt(2.0 / fan_in))
-        if name == "mask_rgb_encoder.conv1.weight":
-            v[:, 3:] *= MASK_CHANNEL_GAIN
-    elif ".bn" in name or "downsample.1" in name:           # BN affine
-        v = r.uniform(0.6, 1.2, shape) if leaf == "weight" else r.standard_normal(shape) * 0.1
-    else:                                                   # conv bias
-        v = r.standard_normal(shape) * 0.05
-    return torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
-
-
-def _apply_calibration(sd, calib):
-    for k, v in calib.items():
-        if k.startswith("gain:"):
-            name = k[5:]
-            sd[name + ".weight"] = sd[name + ".weight"] * float(v)
-            if name + ".bias" in sd:
-                sd[name + ".bias"] = sd[name + ".bias"] * float(v)
-        else:
-            assert sd[k].shape == v.shape, k
-            sd[k] = v.clone()
-
-
-def _load_calibration(tag, seed):
-    path = os.path.join(GOLDEN_DIR, f"{tag}_seed{seed}.npz")
-    with np.load(path) as z:
-        return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
-
-
-def make_prop_state(seed=0, calib="golden"):
-    """Synthetic PropagationNetwork state_dict.  calib: 'golden' applies the committed
-    calibration (BN running stats + per-conv gains), None leaves mean=0/var=1/gain=1."""
-    sd = OrderedDict((k, _draw(k, shp, seed)) for k, shp in prop_spec().items())
-    if calib == "golden":
-        calib = _load_calibration("calib_prop", seed)
-    if calib:
-        _apply_calibration(sd, calib)
-    return sd
-
-
-def make_fuse_state(seed=0, calib="golden"):
-    sd = OrderedDict((k, _draw("fuse." + k, shp, seed)) for k, shp in fuse_spec().items())
-    if calib == "golden":
-        calib = _load_calibration("calib_fuse", seed)
-    if calib:
-        _apply_calibration(sd, calib)
-    return sd
-
-
-def state_fingerprint(sd):
-    """Cheap cross-machine identity check of a generated state dict."""
-    acc = 0.0
-    for k, v in sd.items():
-        if v.dtype.is_floating_point:
-            acc += float(v.double().abs().sum()) * ((zlib.crc32(k.encode()) % 97) + 1)
-    return acc
+from mivos_amd.util.synthetic import *          # noqa: F401,F403
+from mivos_amd.util.synthetic import (KEY_STD, LOGIT_STD, _apply_calibration, make_fuse_state,  # noqa: F401
+                                      make_prop_state, GOLDEN_DIR, state_fingerprint, prop_spec, fuse_spec)
 
 
 def calibrate(seed=0, size=(128, 160)):
