@@ -170,8 +170,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 }
 
 // ---- Cout == 1 (decoder.pred 256->1, FusionNet final 32->1): a GEMM would waste 31/32 of every MFMA.
-// LPP lanes share one output pixel, each lane reduces 32 input channels over the KHxKW taps, then a
-// butterfly over the LPP lanes.  Weights (<= 9*256 floats) live in LDS.
+// LPP lanes share one output pixel; per tap they read the pixel's Cin floats as LPP consecutive float4
+// (one full line per 8 lanes), 8 rounds, then a butterfly over the LPP lanes.  Weights (<= 9*256
+// floats) live in LDS.
 template <int LPP>
 __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
@@ -185,18 +186,17 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvP p) {
   const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
   const float *xb = p.x + (long long)img * p.x_ns;
   float acc = 0.f;
-  const int c0 = sub * 32;
   for (int kh = 0; kh < p.KH; ++kh) {
     const int ih = oh * p.stride - p.pad + kh;
     if ((unsigned)ih >= (unsigned)p.H) continue;
     for (int kw = 0; kw < p.KW; ++kw) {
       const int iw = ow * p.stride - p.pad + kw;
       if ((unsigned)iw >= (unsigned)p.W) continue;
-      const f32x4 *px = reinterpret_cast<const f32x4 *>(xb + ((long long)ih * p.W + iw) * p.x_ps + c0);
-      const f32x4 *pw = reinterpret_cast<const f32x4 *>(wl + (kh * p.KW + kw) * p.Cin + c0);
+      const f32x4 *px = reinterpret_cast<const f32x4 *>(xb + ((long long)ih * p.W + iw) * p.x_ps) + sub;
+      const f32x4 *pw = reinterpret_cast<const f32x4 *>(wl + (kh * p.KW + kw) * p.Cin) + sub;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        f32x4 v = px[q], w4 = pw[q];
+        f32x4 v = px[q * LPP], w4 = pw[q * LPP];
         if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         acc = fmaf(v.x, w4.x, acc); acc = fmaf(v.y, w4.y, acc);
         acc = fmaf(v.z, w4.z, acc); acc = fmaf(v.w, w4.w, acc);

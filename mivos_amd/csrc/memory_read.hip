@@ -25,7 +25,7 @@ constexpr int QT = 128;     // queries per workgroup
 constexpr int KT = 32;      // memory positions per tile
 constexpr int KLD = 132;    // LDS pitch of a key row (floats)
 constexpr int CAP = 112;    // candidate slots per query
-constexpr int CAP_TRIGGER = CAP - 32;
+constexpr int CAP_TRIGGER = CAP - 16;   // a half-tile adds at most 16 candidates per query
 constexpr int MAX_SPLIT = 8;
 constexpr int MAX_TOPK = 64;
 
@@ -44,17 +44,26 @@ __device__ __forceinline__ uint32_t cand_index(uint64_t c) { return 0xffffffffu 
 
 // Exact top-k of one query's candidate buffer, executed by the owning wave (all 64 lanes).
 // Leaves the survivors sorted (best first) in slots [0, min(n,k)), updates cnt / tau.
-__device__ __forceinline__ void compact_query(volatile uint64_t *buf, volatile int *cnt, volatile float *tau, int k,
-                                              int lane) {
+// All-pairs rank: lane l owns entries l and l+64 and counts how many of the n entries beat them; the
+// entries are streamed as 16-byte LDS broadcasts (2 candidates per ds_read_b128).  Only the owning wave
+// touches a query's buffer, LDS ops of one wave execute in order, so no barrier is needed — the asm
+// statements only stop the compiler from caching LDS values across the wave-level hand-offs.
+__device__ __forceinline__ void compact_query(uint64_t *buf, int *cnt, float *tau, int k, int lane) {
+  asm volatile("" ::: "memory");
   const int n = *cnt;
   const uint64_t e0 = lane < n ? buf[lane] : 0ull;
   const uint64_t e1 = lane + 64 < n ? buf[lane + 64] : 0ull;
   int r0 = 0, r1 = 0;
-  for (int i = 0; i < n; ++i) {
-    const uint64_t c = buf[i];  // same address in every lane: LDS broadcast
-    r0 += c > e0;
-    r1 += c > e1;
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2 *b2 = reinterpret_cast<const u64x2 *>(buf);
+#pragma unroll 4
+  for (int i = 0; i < n; i += 2) {
+    u64x2 c = b2[i >> 1];
+    if (i + 1 >= n) c.y = 0ull;
+    r0 += (c.x > e0) + (c.y > e0);
+    r1 += (c.x > e1) + (c.y > e1);
   }
+  asm volatile("" ::: "memory");
   if (lane < n && r0 < k) buf[r0] = e0;
   if (lane + 64 < n && r1 < k) buf[r1] = e1;
   if (n >= k) {
@@ -62,6 +71,7 @@ __device__ __forceinline__ void compact_query(volatile uint64_t *buf, volatile i
     if (lane + 64 < n && r1 == k - 1) *tau = cand_score(e1);
   }
   if (lane == 0) *cnt = n < k ? n : k;
+  asm volatile("" ::: "memory");
 }
 
 __global__ __launch_bounds__(256) void memread_select_kernel(const float *__restrict__ keys, long long keys_ostride,
@@ -132,23 +142,29 @@ __global__ __launch_bounds__(256) void memread_select_kernel(const float *__rest
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], qreg[u][s], acc, 0, 0, 0);
     }
 
-    // make room: a tile can add at most 32 candidates to a query
-    const int mycnt = *(volatile int *)(cnt + qslot);
-    if (__any(mycnt > CAP_TRIGGER)) {
-      for (int qs = 0; qs < 32; ++qs) {
-        const int s = wave * 32 + qs;
-        if (*(volatile int *)(cnt + s) > CAP_TRIGGER)
-          compact_query(cand + s * CAP, cnt + s, tau + s, top_k, lane);
-      }
-      my_tau = *(volatile float *)(tau + qslot);
-    }
+    // append in two halves of 8 registers; before each half make room: a half adds <= 16 per query
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long long m = kb + mfma32_row(r, lane);
-      const float s = acc[r];
-      if (m < c1 && s > my_tau) {
-        const int pos = atomicAdd(cnt + qslot, 1);
-        cand[qslot * CAP + pos] = pack_cand(s, (uint32_t)m);
+    for (int half = 0; half < 2; ++half) {
+      asm volatile("" ::: "memory");
+      const int mycnt = cnt[qslot];
+      unsigned long long need = __ballot(mycnt > CAP_TRIGGER) & 0xffffffffull;
+      if (need) {
+        while (need) {
+          const int s = wave * 32 + __builtin_ctzll(need);
+          need &= need - 1;
+          compact_query(cand + s * CAP, cnt + s, tau + s, top_k, lane);
+        }
+        my_tau = tau[qslot];
+      }
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = half * 8 + rr;
+        const long long m = kb + mfma32_row(r, lane);
+        const float s = acc[r];
+        if (m < c1 && s > my_tau) {
+          const int pos = atomicAdd(cnt + qslot, 1);
+          cand[qslot * CAP + pos] = pack_cand(s, (uint32_t)m);
+        }
       }
     }
   }
@@ -158,8 +174,8 @@ __global__ __launch_bounds__(256) void memread_select_kernel(const float *__rest
     compact_query(cand + s * CAP, cnt + s, tau + s, top_k, lane);
     const int qq = blockIdx.x * QT + s;
     if (qq < n_q && lane < top_k) {
-      const int n = *(volatile int *)(cnt + s);
-      const uint64_t v = lane < n ? *(volatile uint64_t *)(cand + s * CAP + lane) : 0ull;
+      const int n = cnt[s];
+      const uint64_t v = lane < n ? cand[s * CAP + lane] : 0ull;
       cand_out[(((long long)obj * n_split + split) * n_q + qq) * top_k + lane] = v;
     }
   }
