@@ -1,0 +1,63 @@
+"""Run the reference's own entry scripts on top of the MI355X engine, unchanged.
+
+    python -m mivos_amd.dropin /path/to/MiVOS/eval_interactive_davis.py --davis ... --output ...
+    python -m mivos_amd.dropin /path/to/MiVOS/interactive_gui.py --images ...
+
+``install()`` registers this package's modules under the import names the reference's scripts use
+(`eval_interactive_davis.py:11-15`, `interactive_gui.py:29-35`, `davis_processor.py:7-9`):
+
+    inference_core, model.propagation.prop_net, model.propagation.modules, model.fusion_net,
+    model.aggregate, model.attn_network, util.tensor_util
+
+Everything else of the reference (``model.s2m``, ``interact``, ``dataset``, ``davis_processor`` ...) keeps
+resolving to the reference tree, which is appended to the package search paths of ``model`` / ``util``.
+"""
+import importlib
+import os
+import runpy
+import sys
+
+ALIASES = {
+    "inference_core": "mivos_amd.inference_core",
+    "model.propagation.prop_net": "mivos_amd.model.propagation.prop_net",
+    "model.propagation.modules": "mivos_amd.model.propagation.modules",
+    "model.fusion_net": "mivos_amd.model.fusion_net",
+    "model.aggregate": "mivos_amd.model.aggregate",
+    "model.attn_network": "mivos_amd.model.attn_network",
+    "util.tensor_util": "mivos_amd.util.tensor_util",
+}
+PACKAGES = {"model": "mivos_amd.model", "model.propagation": "mivos_amd.model.propagation", "util": "mivos_amd.util"}
+
+
+def install(reference_root=None):
+    """Alias the engine's modules to the reference's import names.  With ``reference_root`` the
+    reference's remaining sub-modules (model/s2m, util/palette ...) stay importable."""
+    for ref_name, ours in PACKAGES.items():
+        pkg = importlib.import_module(ours)
+        if reference_root:
+            extra = os.path.join(reference_root, *ref_name.split("."))
+            if os.path.isdir(extra) and extra not in pkg.__path__:
+                pkg.__path__.append(extra)
+        sys.modules[ref_name] = pkg
+    for ref_name, ours in ALIASES.items():
+        mod = importlib.import_module(ours)
+        sys.modules[ref_name] = mod
+        parent, _, leaf = ref_name.rpartition(".")
+        if parent:
+            setattr(sys.modules[parent], leaf, mod)
+    if reference_root and reference_root not in sys.path:
+        sys.path.append(reference_root)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv:
+        raise SystemExit(__doc__)
+    script = os.path.abspath(argv[0])
+    install(os.path.dirname(script))
+    sys.argv = [script] + argv[1:]
+    runpy.run_path(script, run_name="__main__")
+
+
+if __name__ == "__main__":
+    main()
