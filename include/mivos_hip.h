@@ -67,6 +67,12 @@ typedef struct {
   int32_t split;      /* see above; set to Cout when y2 is NULL                                   */
   int32_t relu_in;    /* apply max(0,.) to x while loading (pre-activation ResBlock)              */
   int32_t relu_out;   /* apply max(0,.) before the store                                          */
+  int32_t precision;  /* 0: exact fp32 MFMA, w = fp32 OHWI.
+                         1: error-compensated fp16 MFMA ("f16x3"): x is split on the fly into fp16 hi + lo,
+                            w points to weights packed by mivos_pack_weights_f16x3 (hi/lo fp16, scaled by a
+                            power of two 2^s; the caller folds 2^-s into `scale`); acc is fp32 and
+                            sums hi*hi + hi*lo + lo*hi, i.e. ~2^-22 relative product error (fp32 class).
+                            Cout == 1 layers always take the fp32 dot-product kernel (w = fp32 OHWI).   */
   int64_t x_nstride, x_pstride;
   int64_t y_nstride, y_pstride;
   int64_t y2_nstride, y2_pstride;
@@ -74,6 +80,11 @@ typedef struct {
 } mivos_conv_desc;
 
 int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream);
+/* Pack OHWI fp32 weights [Cout][Ktot] for precision 1: out[Cout][Kpad/4][8 halves] = per 4 consecutive k
+ * the 4 fp16 "hi" parts of w*mult followed by the 4 fp16 "lo" parts (w*mult - hi); Kpad = Ktot rounded up
+ * to a multiple of 64 (zero filled).  mult must be a power of two (exact scaling). out: Cout*Kpad*4 bytes. */
+int mivos_pack_weights_f16x3(const float *w, void *out, int Cout, int Ktot, float mult, void *stream);
+
 /* Which kernel instantiation mivos_conv2d_fused picks for M = N*Ho*Wo output pixels and Cout channels
  * (0: 128x128 tile, 1: 64x64, 2: 128x32, 3: 128x64, 4: Cout==1 dot product) — for profilers/benchmarks. */
 int mivos_conv2d_variant(int M, int Cout);

@@ -18,7 +18,7 @@ class ConvDesc(C.Structure):
     _fields_ = [("x", vp), ("w", vp), ("scale", vp), ("bias", vp), ("res", vp), ("y", vp), ("y2", vp),
                 ("N", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("KH", i32), ("KW", i32),
                 ("stride", i32), ("pad", i32), ("Ho", i32), ("Wo", i32), ("split", i32),
-                ("relu_in", i32), ("relu_out", i32),
+                ("relu_in", i32), ("relu_out", i32), ("precision", i32),
                 ("x_nstride", i64), ("x_pstride", i64), ("y_nstride", i64), ("y_pstride", i64),
                 ("y2_nstride", i64), ("y2_pstride", i64), ("res_nstride", i64), ("res_pstride", i64)]
 
@@ -34,6 +34,7 @@ PROTOTYPES = {
     "mivos_last_error": (C.c_char_p, []),
     "mivos_device_check": (C.c_int, [C.c_int]),
     "mivos_conv2d_fused": (C.c_int, [C.POINTER(ConvDesc), vp]),
+    "mivos_pack_weights_f16x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "mivos_conv2d_variant": (C.c_int, [C.c_int, C.c_int]),
     "mivos_maxpool3x3s2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_upsample2x_add": (C.c_int, [vp, i64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -1,0 +1,30 @@
+// Kernel-side parameter block shared by the convolution kernels.
+#pragma once
+#include "common.h"
+
+namespace mivos {
+
+struct ConvP {
+  const float *x, *w, *scale, *bias, *res;
+  float *y, *y2;
+  int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, split, relu_in, relu_out;
+  int log2Cin, M, Ktot, HoWo, tiles_n;
+  long long x_ns, x_ps, y_ns, y_ps, y2_ns, y2_ps, r_ns, r_ps;
+};
+
+
+// Tile selection shared by the fp32 and the fp16x3 implicit-GEMM kernels.
+// 0: 128x128 (best MFMA:LDS ratio, needs >= ~1 workgroup per CU), 1: 64x64, 2: 128x32 (Cout <= 32),
+// 3: 128x64 (Cout <= 64, many pixels), 4: Cout == 1 dot-product kernel.
+inline int select_variant(int M, int Cout) {
+  if (Cout == 1) return 4;
+  if (Cout <= 32) return 2;
+  if (Cout <= 64) return cdiv(M, 128) >= 200 ? 3 : 1;
+  return (long long)cdiv(M, 128) * cdiv(Cout, 128) >= 200 ? 0 : 1;
+}
+
+// fills ConvP from the public descriptor after validating it; returns a status code
+int conv_params_from_desc(const mivos_conv_desc *d, ConvP &p);
+int launch_conv_f16x3(ConvP &p, hipStream_t st);
+
+}  // namespace mivos

@@ -1,0 +1,248 @@
+// Error-compensated fp16 implicit-GEMM convolution for gfx950 ("f16x3").
+//
+// The exact-fp32 MFMA (conv_igemm.hip) tops out at 157 TFLOP/s; the 16-bit matrix cores are 16x faster but
+// plain fp16/bf16 operands miss the 1e-3 logit budget by 16-100x.  Here every fp32 operand
+// is split into two fp16 numbers, x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (22 significant bits),
+// and the product is accumulated in fp32 as
+//        x*w  ~=  x_hi*w_hi + x_hi*w_lo + x_lo*w_hi            (dropped: x_lo*w_lo ~ 2^-22 |x*w|)
+// i.e. 3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block = 16/3 = 5.3x the fp32-MFMA rate at fp32-class
+// accuracy (measured: same error vs an fp64 run as the fp32 path).  Weights are split offline
+// (mivos_pack_weights_f16x3) after an exact power-of-two scaling that lifts their lo parts out of the fp16
+// subnormal range; activations stay fp32 in HBM and are split while they are staged into LDS, so no other
+// kernel or tensor layout changes.
+//
+// Tiling: block tile BM x BN x 64, 4 waves, wave tile of 32x32 MFMA tiles.  LDS holds four fp16 images per
+// stage (A_hi, A_lo, B_hi, B_lo; K contiguous, 72-half pitch => conflict-free ds_read_b128 fragment reads,
+// one read = the 8 halves a lane feeds to one MFMA).  One LDS stage + register prefetch of the next stage
+// (two barriers per 64-deep step); two workgroups per CU overlap each other's barrier/convert phases.
+#include "conv_common.h"
+
+namespace mivos {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int BKH = 64;     // k per stage
+constexpr int PITCH = 72;   // halves per LDS row (64 + 8 pad = 144 B)
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvP p, int kpad4) {
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int MT = TM / 32, NT = TN / 32;
+  constexpr int RP = 16;                       // rows staged per pass (256 threads / 16 float4 per row)
+  constexpr int A_LD = BM / RP, B_LD = BN / RP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *Ah = reinterpret_cast<_Float16 *>(smem_raw);
+  _Float16 *Al = Ah + BM * PITCH;
+  _Float16 *Bh = Al + BM * PITCH;
+  _Float16 *Bl = Bh + BN * PITCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int bid = blockIdx.x;
+  const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
+
+  const int k4 = tid & 15, lrow = tid >> 4;
+  const float *a_base[A_LD];
+  int a_ih0[A_LD], a_iw0[A_LD];
+  bool a_ok[A_LD];
+#pragma unroll
+  for (int j = 0; j < A_LD; ++j) {
+    int m = m0 + lrow + RP * j;
+    a_ok[j] = m < p.M;
+    int mm = a_ok[j] ? m : 0;
+    int n = mm / p.HoWo, rem = mm - n * p.HoWo;
+    int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+    a_ih0[j] = oh * p.stride - p.pad;
+    a_iw0[j] = ow * p.stride - p.pad;
+    a_base[j] = p.x + (long long)n * p.x_ns;
+  }
+  const f32x4 *b_ptr[B_LD];   // 16-byte units: [hi0..3 | lo0..3] per 4 k
+  bool b_ok[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    int n = n0 + lrow + RP * j;
+    b_ok[j] = n < p.Cout;
+    b_ptr[j] = reinterpret_cast<const f32x4 *>(p.w) + (long long)(b_ok[j] ? n : 0) * kpad4 + k4;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  f32x4 ra[A_LD], rb[B_LD];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  auto gload = [&](int k0) {
+    const int k = k0 + 4 * k4;
+    const bool kok = k < p.Ktot;
+    const int tap = k >> p.log2Cin, c = k & (p.Cin - 1);
+    int kh, kw;
+    if (p.KW == 1) { kh = tap; kw = 0; }
+    else if (p.KW == 3) { kh = tap / 3; kw = tap - 3 * kh; }
+    else { kh = tap / p.KW; kw = tap - p.KW * kh; }
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+      const bool ok = a_ok[j] && kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      f32x4 v = zero4;
+      if (ok) v = *reinterpret_cast<const f32x4 *>(a_base[j] + ((long long)ih * p.W + iw) * p.x_ps + c);
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      f32x4 v = zero4;
+      if (b_ok[j]) v = b_ptr[j][k0 >> 2];        // weights are zero padded up to kpad
+      rb[j] = v;
+    }
+  };
+  auto lwrite = [&]() {
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      f32x4 v = ra[j];
+      if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      h4 hi, lo;
+      hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
+      lo.x = (_Float16)(v.x - (float)hi.x); lo.y = (_Float16)(v.y - (float)hi.y);
+      lo.z = (_Float16)(v.z - (float)hi.z); lo.w = (_Float16)(v.w - (float)hi.w);
+      const int off = (lrow + RP * j) * PITCH + 4 * k4;
+      *reinterpret_cast<h4 *>(Ah + off) = hi;
+      *reinterpret_cast<h4 *>(Al + off) = lo;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      const int off = (lrow + RP * j) * PITCH + 4 * k4;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 h, l;
+      h.x = rb[j].x; h.y = rb[j].y; l.x = rb[j].z; l.y = rb[j].w;
+      *reinterpret_cast<f32x2 *>(Bh + off) = h;
+      *reinterpret_cast<f32x2 *>(Bl + off) = l;
+    }
+  };
+
+  const int nk = (p.Ktot + BKH - 1) / BKH;
+  gload(0);
+  const int frag = (lane & 31) * PITCH + 8 * (lane >> 5);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();                       // everybody is done reading the previous stage
+    lwrite();
+    __syncthreads();
+    if (kt + 1 < nk) gload((kt + 1) * BKH);
+    const _Float16 *pAh = Ah + wm * TM * PITCH + frag, *pAl = Al + wm * TM * PITCH + frag;
+    const _Float16 *pBh = Bh + wn * TN * PITCH + frag, *pBl = Bl + wn * TN * PITCH + frag;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      h8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        ah[i] = *reinterpret_cast<const h8 *>(pAh + i * 32 * PITCH + kk * 16);
+        al[i] = *reinterpret_cast<const h8 *>(pAl + i * 32 * PITCH + kk * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        bh[i] = *reinterpret_cast<const h8 *>(pBh + i * 32 * PITCH + kk * 16);
+        bl[i] = *reinterpret_cast<const h8 *>(pBl + i * 32 * PITCH + kk * 16);
+      }
+      // small cross terms first, then the main product; tiles interleaved so that consecutive MFMAs
+      // never wait on the same accumulator
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * TN + j * 32 + (lane & 31);
+    if (n >= p.Cout) continue;
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float bi = p.bias ? p.bias[n] : 0.f;
+    float *dst;
+    long long d_ns, d_ps;
+    int dn;
+    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_ps = p.y_ps; dn = n; }
+    else { dst = p.y2; d_ns = p.y2_ns; d_ps = p.y2_ps; dn = n - p.split; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM + i * 32 + mfma32_row(r, lane);
+        if (m >= p.M) continue;
+        const int img = m / p.HoWo, pix = m - img * p.HoWo;
+        float v = acc[i][j][r] * sc + bi;
+        if (p.res) v += p.res[(long long)img * p.r_ns + (long long)pix * p.r_ps + n];
+        if (p.relu_out) v = fmaxf(v, 0.f);
+        dst[(long long)img * d_ns + (long long)pix * d_ps + dn] = v;
+      }
+    }
+  }
+}
+
+__global__ void pack_weights_f16x3_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, int Cout, int Ktot,
+                                          int Kpad, float mult) {
+  const long long total = (long long)Cout * (Kpad / 4);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / (Kpad / 4)), q = (int)(i - (long long)n * (Kpad / 4));
+    _Float16 *o = out + i * 8;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = 4 * q + t;
+      const float v = k < Ktot ? w[(long long)n * Ktot + k] * mult : 0.f;
+      const _Float16 hi = (_Float16)v;
+      o[t] = hi;
+      o[4 + t] = (_Float16)(v - (float)hi);
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static int launch_f16x3(ConvP &p, hipStream_t st) {
+  const int tiles_m = cdiv(p.M, BM);
+  p.tiles_n = cdiv(p.Cout, BN);
+  const size_t lds = 2ull * (BM + BN) * PITCH * sizeof(_Float16);
+  auto kern = conv_f16x3_kernel<BM, BN, WGM, WGN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(conv_f16x3): %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int kpad4 = cdiv(p.Ktot, BKH) * BKH / 4;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(256), lds, st, p, kpad4);
+  return check_launch("conv_f16x3");
+}
+
+int launch_conv_f16x3(ConvP &p, hipStream_t st) {
+  switch (select_variant(p.M, p.Cout)) {
+    case 0: return launch_f16x3<128, 128, 2, 2>(p, st);
+    case 1: return launch_f16x3<64, 64, 2, 2>(p, st);
+    case 2: return launch_f16x3<128, 32, 4, 1>(p, st);
+    default: return launch_f16x3<128, 64, 2, 2>(p, st);
+  }
+}
+
+}  // namespace mivos
+
+using namespace mivos;
+
+extern "C" int mivos_pack_weights_f16x3(const float *w, void *out, int Cout, int Ktot, float mult, void *stream) {
+  if (!w || !out || Cout < 1 || Ktot < 4 || (Ktot & 3)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "pack_weights_f16x3: bad arguments");
+  const int Kpad = cdiv(Ktot, BKH) * BKH;
+  hipLaunchKernelGGL(pack_weights_f16x3_kernel, dim3(cdiv((long long)Cout * (Kpad / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     w, (_Float16 *)out, Cout, Ktot, Kpad, mult);
+  return check_launch("pack_weights_f16x3");
+}

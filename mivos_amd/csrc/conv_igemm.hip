@@ -14,17 +14,9 @@
 // Global->LDS goes through registers (float4 per lane, one 128-B line per 8 lanes) because conv
 // zero-padding needs per-element predication; tile k+1 is fetched while tile k is multiplied.
 // Epilogue (fused): * scale[c] + bias[c] (+ residual) (ReLU) and a two-destination channel split.
-#include "common.h"
+#include "conv_common.h"
 
 namespace mivos {
-
-struct ConvP {
-  const float *x, *w, *scale, *bias, *res;
-  float *y, *y2;
-  int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, split, relu_in, relu_out;
-  int log2Cin, M, Ktot, HoWo, tiles_n;
-  long long x_ns, x_ps, y_ns, y_ps, y2_ns, y2_ps, r_ns, r_ps;
-};
 
 constexpr int BK = 32;   // k-chunk (floats) per pipeline stage
 constexpr int LDK = 36;  // LDS row pitch in floats (32 + 4 pad)
@@ -229,20 +221,12 @@ static int launch_igemm(ConvP &p, hipStream_t st) {
   return check_launch("conv_igemm");
 }
 
-// Tile selection.  0: 128x128 (best MFMA:LDS ratio, needs >= ~1 workgroup per CU), 1: 64x64,
-// 2: 128x32 (Cout <= 32), 3: 128x64 (Cout <= 64, many pixels), 4: Cout == 1 dot-product kernel.
-static int select_variant(int M, int Cout) {
-  if (Cout == 1) return 4;
-  if (Cout <= 32) return 2;
-  if (Cout <= 64) return cdiv(M, 128) >= 200 ? 3 : 1;
-  return (long long)cdiv(M, 128) * cdiv(Cout, 128) >= 200 ? 0 : 1;
-}
-
 }  // namespace mivos
 
 using namespace mivos;
 
-extern "C" int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream) {
+namespace mivos {
+int conv_params_from_desc(const mivos_conv_desc *d, ConvP &p) {
   if (!d || !d->x || !d->w || !d->y) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: null pointer");
   if (d->Cin < 4 || (d->Cin & (d->Cin - 1))) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: Cin=%d must be a power of two >= 4", d->Cin);
   if (d->KH != d->KW || d->KH < 1 || d->stride < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: unsupported kernel %dx%d stride %d", d->KH, d->KW, d->stride);
@@ -252,7 +236,6 @@ extern "C" int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream) {
     return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: x / w must be 16-byte aligned with strides %% 4 == 0");
   if (d->N < 1 || d->Cout < 1 || (long long)d->N * d->Ho * d->Wo > 0x7fffffffLL) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: bad N/Cout");
   const bool dual = d->y2 != nullptr && d->split < d->Cout;
-  ConvP p;
   p.x = d->x; p.w = d->w; p.scale = d->scale; p.bias = d->bias; p.res = d->res; p.y = d->y; p.y2 = d->y2;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
   p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
@@ -262,7 +245,16 @@ extern "C" int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream) {
   p.HoWo = d->Ho * d->Wo; p.M = d->N * p.HoWo; p.Ktot = d->KH * d->KW * d->Cin; p.tiles_n = 1;
   p.x_ns = d->x_nstride; p.x_ps = d->x_pstride; p.y_ns = d->y_nstride; p.y_ps = d->y_pstride;
   p.y2_ns = d->y2_nstride; p.y2_ps = d->y2_pstride; p.r_ns = d->res_nstride; p.r_ps = d->res_pstride;
+  return MIVOS_OK;
+}
+}  // namespace mivos
+
+extern "C" int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream) {
+  ConvP p;
+  int rc = conv_params_from_desc(d, p);
+  if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (d->precision == 1 && p.Cout > 1) return launch_conv_f16x3(p, st);
 
   if (p.Cout == 1) {
     if (p.Cin % 32) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: Cout=1 path needs Cin %% 32 == 0");

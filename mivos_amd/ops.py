@@ -13,6 +13,9 @@ from . import _lib
 from ._lib import ConvDesc, InterleaveDesc, MivosHipError, check
 
 _checked_devices = set()
+# "f16x3": error-compensated fp16 MFMA convolutions (3 products per term, fp32-class accuracy, 5.3x the
+# fp32-MFMA rate); "f32": exact fp32 MFMA everywhere (the verification path).
+CONV_PRECISION = "f16x3"
 # bench.py sets this to a list to time every conv launch with HIP events on the launch stream:
 # entries (kernel variant, algorithmic FLOPs = 2*M*Cout*KH*KW*Cin, start event, end event)
 PROFILE = None
@@ -50,7 +53,7 @@ def _nhwc_strides(t):
 
 class ConvLayer:
     """Device-resident packed convolution: OHWI weights (+ folded BN scale / bias)."""
-    __slots__ = ("w", "scale", "bias", "cin", "cout", "k", "stride", "pad", "split")
+    __slots__ = ("w", "scale", "bias", "cin", "cout", "k", "stride", "pad", "split", "w16", "scale16")
 
     def __init__(self, w_ohwi, scale, bias, stride, pad, split=None):
         self.w = w_ohwi.contiguous()
@@ -58,6 +61,24 @@ class ConvLayer:
         self.scale, self.bias = scale, bias
         self.stride, self.pad = stride, pad
         self.split = self.cout if split is None else split
+        self.w16 = self.scale16 = None
+
+    def f16x3(self):
+        """(packed hi/lo fp16 weights, epilogue scale incl. the 2^-s of the weight pre-scaling); built on
+        first use on the GPU the layer lives on."""
+        if self.w16 is None:
+            import math
+            _ensure_device(self.w)
+            ktot = self.k * self.k * self.cin
+            kpad = (ktot + 63) // 64 * 64
+            wmax = float(self.w.abs().max())
+            s = 14 - math.floor(math.log2(wmax)) if wmax > 0 else 0     # max |w * 2^s| in [2^14, 2^15)
+            mult = 2.0 ** s
+            w16 = torch.empty(self.cout * kpad * 4, dtype=torch.uint8, device=self.w.device)
+            check(_lib.load().mivos_pack_weights_f16x3(self.w.data_ptr(), w16.data_ptr(), self.cout, ktot, mult, _stream()))
+            base = self.scale if self.scale is not None else torch.ones(self.cout, dtype=torch.float32, device=self.w.device)
+            self.w16, self.scale16 = w16, (base * (1.0 / mult)).contiguous()
+        return self.w16, self.scale16
 
     @staticmethod
     def pack(weight, bias=None, bn=None, stride=1, pad=0, cin_pad=None, eps=1e-5):
@@ -90,6 +111,7 @@ class ConvLayer:
             v = getattr(self, n)
             if v is not None:
                 setattr(self, n, v.to(device))
+        self.w16 = self.scale16 = None
         return self
 
 
@@ -108,8 +130,12 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None):
     if dual and out2 is None:
         out2 = torch.empty((n, ho, wo, L.cout - L.split), dtype=torch.float32, device=x.device)
     d = ConvDesc()
-    d.x, d.w = _f32(x).data_ptr(), L.w.data_ptr()
-    d.scale = L.scale.data_ptr() if L.scale is not None else None
+    if CONV_PRECISION == "f16x3" and L.cout > 1:
+        w16, scale16 = L.f16x3()
+        d.x, d.w, d.scale, d.precision = _f32(x).data_ptr(), w16.data_ptr(), scale16.data_ptr(), 1
+    else:
+        d.x, d.w, d.precision = _f32(x).data_ptr(), L.w.data_ptr(), 0
+        d.scale = L.scale.data_ptr() if L.scale is not None else None
     d.bias = L.bias.data_ptr() if L.bias is not None else None
     d.y = out.data_ptr()
     d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = n, h, w, cin, L.cout, L.k, L.k

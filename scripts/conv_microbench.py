@@ -31,6 +31,8 @@ SHAPES = [  # name, N, H, W, Cin, Cout, k, stride
     ("fusion head 3x3 32->1 b5", 5, 480, 864, 32, 1, 3, 1),
 ]
 only = sys.argv[1] if len(sys.argv) > 1 else None
+ops.CONV_PRECISION = os.environ.get("PREC", ops.CONV_PRECISION)
+print("precision", ops.CONV_PRECISION)
 reps = int(os.environ.get("REPS", "10"))
 tot_t = tot_f = 0.0
 for name, n, h, w, cin, cout, k, s in SHAPES:

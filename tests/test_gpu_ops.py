@@ -43,8 +43,16 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=["f32", "f16x3"])
+def precision(request):
+    """Both convolution back-ends: exact fp32 MFMA and error-compensated fp16 MFMA (3 products/term)."""
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, request.param
+    yield request.param
+    ops.CONV_PRECISION = old
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c[:8])))
-def test_conv2d_fused(case):
+def test_conv2d_fused(case, precision):
     n, cin, cout, k, stride, pad, h, w, relu_in, relu_out, use_res, use_bn = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     x = torch.randn(n, cin, h, w, generator=g)
@@ -67,10 +75,12 @@ def test_conv2d_fused(case):
     L = ConvLayer.pack(wt, b, bn, stride, pad).to(DEV)
     got = ops.conv(nhwc(x).to(DEV), L, relu_in=relu_in, relu_out=relu_out, res=None if res is None else nhwc(res).to(DEV))
     torch.cuda.synchronize()
-    assert rel_err(got.cpu().permute(0, 3, 1, 2), ref) < max(2e-6, 6e-8 * (cin * k * k) ** 0.5)   # fp32 chain over K terms
+    err = rel_err(got.cpu().permute(0, 3, 1, 2), ref)
+    print(f"{precision}: rel err vs fp64 {err:.2e}")
+    assert err < max(2e-6, 6e-8 * (cin * k * k) ** 0.5)   # fp32-class accuracy for both back-ends
 
 
-def test_conv2d_strided_views_split_and_broadcast_residual():
+def test_conv2d_strided_views_split_and_broadcast_residual(precision):
     g = torch.Generator().manual_seed(5)
     n, cin, h, w = 3, 64, 12, 14
     big = torch.randn(n, h, w, 160, generator=g).to(DEV)                  # input is a channel slice
