@@ -29,8 +29,14 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# fp16 MFMA dense peak (2.5 PFLOP/s) / 3 MFMA products per algorithmic multiply-add of the error-compensated
+# f16x3 convolution = the roofline of that kernel in ALGORITHMIC (fp32-equivalent) FLOP/s
+F16X3_PEAK_TFLOPS = 2500.0 / 3
 VARIANT_NAMES = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<64,64,2,2>",
-                 2: "conv_igemm_kernel<128,32,4,1>", 3: "conv_igemm_kernel<128,64,2,2>", 4: "conv_cout1_kernel"}
+                 2: "conv_igemm_kernel<128,32,4,1>", 3: "conv_igemm_kernel<128,64,2,2>", 4: "conv_cout1_kernel",
+                 10: "conv_f16x3_kernel<128,128,2,2>", 11: "conv_f16x3_kernel<64,64,2,2>", 12: "conv_f16x3_kernel<128,32,4,1>",
+                 13: "conv_f16x3_kernel<128,64,2,2>", 14: "conv_cout1_kernel", 15: "conv_f16x3_pipe_kernel<256,256,2,4>",
+                 16: "conv_f16x3_pipe_kernel<128,256,2,4>"}
 
 
 class StepTimer:
@@ -76,8 +82,11 @@ def conv_roofline(samples):
     dom = max(agg.items(), key=lambda kv: kv[1][1])
     v, (flops, secs, n) = dom
     ach = flops / secs / 1e12
-    roof = dict(bound="mfma", kernel=VARIANT_NAMES[v], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, launches_sampled=n,
+    peak = F16X3_PEAK_TFLOPS if v >= 10 else MFMA_F32_PEAK_TFLOPS
+    roof = dict(bound="mfma", kernel=VARIANT_NAMES[v], achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
+                frac=round(ach / peak, 4), traffic=None, launches_sampled=n,
+                peak_note=("algorithmic (fp32-equivalent) FLOP/s; kernel issues 3 fp16 MFMA products per term: 2500/3"
+                           if v >= 10 else "fp32 MFMA dense peak"),
                 avg_launch_us=round(secs / n * 1e6, 2), algorithmic_gflop_per_launch=round(flops / n / 1e9, 3))
     return roof, table
 

@@ -80,14 +80,18 @@ typedef struct {
 } mivos_conv_desc;
 
 int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream);
-/* Pack OHWI fp32 weights [Cout][Ktot] for precision 1: out[Cout][Kpad/4][8 halves] = per 4 consecutive k
- * the 4 fp16 "hi" parts of w*mult followed by the 4 fp16 "lo" parts (w*mult - hi); Kpad = Ktot rounded up
- * to a multiple of 64 (zero filled).  mult must be a power of two (exact scaling). out: Cout*Kpad*4 bytes. */
-int mivos_pack_weights_f16x3(const float *w, void *out, int Cout, int Ktot, float mult, void *stream);
+/* Pack OHWI fp32 weights [Cout][KH][KW][Cin] for precision 1.  out[Cout][Kpad/4][8 halves]: per 4
+ * consecutive K positions the 4 fp16 "hi" parts of w*mult followed by the 4 fp16 "lo" parts
+ * (w*mult - hi); Kpad = KH*KW*Cin rounded up to a multiple of 64 (zero filled).  For Cin % 32 == 0 the
+ * K axis is stored "taps inner" (k' = (c/32)*(KH*KW*32) + tap*32 + c%32), the order in which the f16x3
+ * kernels walk K (L1/L2 reuse across the taps).  mult must be a power of two.  out: Cout*Kpad*4 bytes. */
+int mivos_pack_weights_f16x3(const float *w, void *out, int Cout, int KH, int KW, int Cin, float mult, void *stream);
 
 /* Which kernel instantiation mivos_conv2d_fused picks for M = N*Ho*Wo output pixels and Cout channels
  * (0: 128x128 tile, 1: 64x64, 2: 128x32, 3: 128x64, 4: Cout==1 dot product) — for profilers/benchmarks. */
 int mivos_conv2d_variant(int M, int Cout);
+/* Same for precision 1 (f16x3): additionally 5: 256x256 tile / 8 waves pipelined, 6: 128x256 / 8 waves. */
+int mivos_conv2d_variant_f16x3(int M, int Cout);
 
 /* MaxPool2d(3, stride 2, pad 1) on NHWC (mod_resnet.py:121 / torchvision stem). C % 4 == 0. */
 int mivos_maxpool3x3s2(const float *x, float *y, int N, int H, int W, int C, void *stream);

@@ -34,8 +34,9 @@ PROTOTYPES = {
     "mivos_last_error": (C.c_char_p, []),
     "mivos_device_check": (C.c_int, [C.c_int]),
     "mivos_conv2d_fused": (C.c_int, [C.POINTER(ConvDesc), vp]),
-    "mivos_pack_weights_f16x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    "mivos_pack_weights_f16x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "mivos_conv2d_variant": (C.c_int, [C.c_int, C.c_int]),
+    "mivos_conv2d_variant_f16x3": (C.c_int, [C.c_int, C.c_int]),
     "mivos_maxpool3x3s2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_upsample2x_add": (C.c_int, [vp, i64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_memory_read_workspace_bytes": (i64, [C.c_int, i64, C.c_int, C.c_int]),

@@ -15,12 +15,32 @@
 // stage (A_hi, A_lo, B_hi, B_lo; K contiguous, 72-half pitch => conflict-free ds_read_b128 fragment reads,
 // one read = the 8 halves a lane feeds to one MFMA).  One LDS stage + register prefetch of the next stage
 // (two barriers per 64-deep step); two workgroups per CU overlap each other's barrier/convert phases.
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace mivos {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+// K order of the packed f16x3 weights ("taps inner"): for Cin % 32 == 0 the GEMM K axis is re-ordered to
+//      k' = (c / 32) * (ntaps * 32) + tap * 32 + c % 32
+// so that the KH*KW taps of one 32-channel slab are consecutive K steps: a workgroup then re-reads the same
+// 128 B of every input pixel (shifted by one pixel per tap) within 9 consecutive steps and hits in L1/L2,
+// instead of streaming the whole input once per tap (PMC before: 50 % L2 hit rate, 1.4 GB/launch from
+// beyond L2 on the 129600x256x2304 decoder GEMM).
+__device__ __forceinline__ void decode_k(int k, int cin, int log2cin, int ntaps, bool taps_inner, int &tap, int &c) {
+  if (taps_inner) {
+    const int s = k >> 5;                                   // 32-channel step index
+    const int chunk = ntaps == 9 ? s / 9 : (ntaps == 1 ? s : s / ntaps);
+    tap = s - chunk * ntaps;
+    c = chunk * 32 + (k & 31);
+  } else {
+    tap = k >> log2cin;
+    c = k & (cin - 1);
+  }
+}
 
 constexpr int BKH = 64;     // k per stage
 constexpr int PITCH = 72;   // halves per LDS row (64 + 8 pad = 144 B)
@@ -40,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvP p, int kpad4) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int bid = blockIdx.x;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
 
   const int k4 = tid & 15, lrow = tid >> 4;
@@ -78,10 +98,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvP p, int kpad4) 
   f32x4 ra[A_LD], rb[B_LD];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+  const int ntaps = p.KH * p.KW;
+  const bool taps_inner = (p.Cin & 31) == 0;
   auto gload = [&](int k0) {
     const int k = k0 + 4 * k4;
     const bool kok = k < p.Ktot;
-    const int tap = k >> p.log2Cin, c = k & (p.Cin - 1);
+    int tap, c;
+    decode_k(k, p.Cin, p.log2Cin, ntaps, taps_inner, tap, c);
     int kh, kw;
     if (p.KW == 1) { kh = tap; kw = 0; }
     else if (p.KW == 3) { kh = tap / 3; kw = tap - 3 * kh; }
@@ -192,16 +215,207 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvP p, int kpad4) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pipelined 8-wave variant for the big GEMMs (decoder, mask encoder at batch K).
+// PMC on the 4-wave kernel above (profiles/): MFMA pipe 30 % busy, VALU 35 % busy, and the two never
+// overlap inside a wave because "convert + ds_write" sits between the barriers and the MFMAs after them.
+// Here: block tile up to 256x256, 8 waves (2 per SIMD), K step 32, TWO LDS stages; while the MFMAs of
+// stage t run, the same wave converts and writes stage t+1 (segments interleaved between MFMA groups) and
+// the global loads of stage t+2 are in flight -> one barrier per step.  BN = 256 covers all output
+// channels of the decoder convs, so every activation element is split once per tap instead of twice, and
+// the 128x64 wave tile halves the LDS bytes read per MFMA.
+constexpr int BK2 = 32;     // k per stage
+constexpr int PITCH2 = 40;  // halves per LDS row (32 + 8 pad = 80 B, conflict-free b128 fragment reads)
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(512) void conv_f16x3_pipe_kernel(ConvP p, int kpad4) {
+  static_assert(WGM * WGN == 8, "8 waves per workgroup");
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int MT = TM / 32, NT = TN / 32;
+  constexpr int RP = 64;                       // rows staged per pass (512 threads / 8 float4 per row)
+  constexpr int A_LD = BM / RP, B_LD = BN / RP;
+  constexpr int NSEG = A_LD > B_LD ? A_LD : B_LD;
+  constexpr int STAGE = 2 * (BM + BN) * PITCH2;   // halves per stage: Ah | Al | Bh | Bl
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *lds = reinterpret_cast<_Float16 *>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
+
+  const int k4 = tid & 7, lrow = tid >> 3;
+  const float *a_base[A_LD];
+  int a_ih0[A_LD], a_iw0[A_LD];
+#pragma unroll
+  for (int j = 0; j < A_LD; ++j) {
+    int m = m0 + lrow + RP * j;
+    const bool ok = m < p.M;
+    int mm = ok ? m : 0;
+    int n = mm / p.HoWo, rem = mm - n * p.HoWo;
+    int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+    a_ih0[j] = ok ? oh * p.stride - p.pad : -0x40000000;     // out-of-range rows fail the bounds test
+    a_iw0[j] = ow * p.stride - p.pad;
+    a_base[j] = p.x + (long long)n * p.x_ns;
+  }
+  const f32x4 *b_ptr[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    int n = n0 + lrow + RP * j;
+    b_ptr[j] = reinterpret_cast<const f32x4 *>(p.w) + (long long)(n < p.Cout ? n : p.Cout - 1) * kpad4 + k4;   // columns >= Cout are never stored
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  f32x4 ra[A_LD], rb[B_LD];
+  const bool uniform_tap = (p.Cin & 31) == 0;     // taps-inner K order: a 32-deep step is one tap of one slab
+  const int ntaps = p.KH * p.KW;
+  const float relu_floor = p.relu_in ? 0.f : -INFINITY;
+  const int nk = (p.Ktot + BK2 - 1) / BK2;
+  const int k_last = (nk - 1) * BK2;
+
+  // Branch-free loaders (the main loop must stay ONE basic block so that the scheduler can put the
+  // staging VALU / LDS writes / global loads in the shadow of the MFMAs): invalid taps / rows load from
+  // the tensor base and are zeroed by a select, steps past the end re-load the last step.
+  auto gload = [&](int k0) {
+    k0 = k0 < k_last ? k0 : k_last;
+    int tap, c;
+    if (uniform_tap) { decode_k(k0, p.Cin, p.log2Cin, ntaps, true, tap, c); c += 4 * k4; }   // wave-uniform tap
+    else decode_k(k0 + 4 * k4, p.Cin, p.log2Cin, ntaps, false, tap, c);
+    const bool kok = k0 + 4 * k4 < p.Ktot;
+    int kh, kw;
+    if (p.KW == 1) { kh = tap; kw = 0; }
+    else if (p.KW == 3) { kh = tap / 3; kw = tap - 3 * kh; }
+    else { kh = tap / p.KW; kw = tap - p.KW * kh; }
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+      const bool ok = kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const long long off = ok ? ((long long)ih * p.W + iw) * p.x_ps + c : 0ll;
+      f32x4 v = *reinterpret_cast<const f32x4 *>(a_base[j] + off);
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) rb[j] = b_ptr[j][k0 >> 2];
+  };
+  // convert + write one staging pass (A pass s and B pass s) of the prefetched registers into stage `st`
+  auto lwrite_seg = [&](_Float16 *st, int s) {
+    if (s < A_LD) {
+      f32x4 v = ra[s];
+      v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+      h4 hi, lo;
+      hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
+      lo.x = (_Float16)__builtin_fmaf((float)hi.x, -1.f, v.x); lo.y = (_Float16)__builtin_fmaf((float)hi.y, -1.f, v.y);
+      lo.z = (_Float16)__builtin_fmaf((float)hi.z, -1.f, v.z); lo.w = (_Float16)__builtin_fmaf((float)hi.w, -1.f, v.w);
+      const int off = (lrow + RP * s) * PITCH2 + 4 * k4;
+      *reinterpret_cast<h4 *>(st + off) = hi;
+      *reinterpret_cast<h4 *>(st + BM * PITCH2 + off) = lo;
+    }
+    if (s < B_LD) {
+      const int off = 2 * BM * PITCH2 + (lrow + RP * s) * PITCH2 + 4 * k4;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 h, l;
+      h.x = rb[s].x; h.y = rb[s].y; l.x = rb[s].z; l.y = rb[s].w;
+      *reinterpret_cast<f32x2 *>(st + off) = h;
+      *reinterpret_cast<f32x2 *>(st + BN * PITCH2 + off) = l;
+    }
+  };
+  const int frag = (lane & 31) * PITCH2 + 8 * (lane >> 5);
+  // one 32-deep step on stage `cur`; when STAGE_NEXT, the prefetched registers are converted and written
+  // into `nxt` in segments placed behind the MFMA groups
+  auto step = [&](const _Float16 *cur, _Float16 *nxt, auto stage_next) {
+    constexpr bool STAGE_NEXT = decltype(stage_next)::value;
+    const _Float16 *pA = cur + wm * TM * PITCH2 + frag;
+    const _Float16 *pB = cur + 2 * BM * PITCH2 + wn * TN * PITCH2 + frag;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      h8 bh[NT], bl[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bh[j] = *reinterpret_cast<const h8 *>(pB + j * 32 * PITCH2 + kk * 16);
+        bl[j] = *reinterpret_cast<const h8 *>(pB + BN * PITCH2 + j * 32 * PITCH2 + kk * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const h8 ah = *reinterpret_cast<const h8 *>(pA + i * 32 * PITCH2 + kk * 16);
+        const h8 al = *reinterpret_cast<const h8 *>(pA + BM * PITCH2 + i * 32 * PITCH2 + kk * 16);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+        if (STAGE_NEXT && kk * MT + i < NSEG) lwrite_seg(nxt, kk * MT + i);
+      }
+    }
+    if (STAGE_NEXT) {
+#pragma unroll
+      for (int s = 2 * MT; s < NSEG; ++s) lwrite_seg(nxt, s);
+    }
+  };
+
+  gload(0);
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) lwrite_seg(lds, s);
+  gload(BK2);
+  __syncthreads();
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    step(lds + (kt & 1) * STAGE, lds + ((kt + 1) & 1) * STAGE, std::true_type{});
+    gload((kt + 2) * BK2);
+    __syncthreads();
+  }
+  step(lds + ((nk - 1) & 1) * STAGE, nullptr, std::false_type{});
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * TN + j * 32 + (lane & 31);
+    if (n >= p.Cout) continue;
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float bi = p.bias ? p.bias[n] : 0.f;
+    float *dst;
+    long long d_ns, d_ps;
+    int dn;
+    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_ps = p.y_ps; dn = n; }
+    else { dst = p.y2; d_ns = p.y2_ns; d_ps = p.y2_ps; dn = n - p.split; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM + i * 32 + mfma32_row(r, lane);
+        if (m >= p.M) continue;
+        const int img = m / p.HoWo, pix = m - img * p.HoWo;
+        float v = acc[i][j][r] * sc + bi;
+        if (p.res) v += p.res[(long long)img * p.r_ns + (long long)pix * p.r_ps + n];
+        if (p.relu_out) v = fmaxf(v, 0.f);
+        dst[(long long)img * d_ns + (long long)pix * d_ps + dn] = v;
+      }
+    }
+  }
+}
+
 __global__ void pack_weights_f16x3_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, int Cout, int Ktot,
-                                          int Kpad, float mult) {
+                                          int Kpad, float mult, int cin, int ntaps) {
+  const bool taps_inner = (cin & 31) == 0;
   const long long total = (long long)Cout * (Kpad / 4);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int n = (int)(i / (Kpad / 4)), q = (int)(i - (long long)n * (Kpad / 4));
     _Float16 *o = out + i * 8;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int k = 4 * q + t;
-      const float v = k < Ktot ? w[(long long)n * Ktot + k] * mult : 0.f;
+      const int k = 4 * q + t;                      // position in the kernel's K order
+      int src = k;                                  // position in OHWI order: tap * cin + c
+      if (taps_inner && k < Ktot) {
+        const int s = k >> 5, chunk = s / ntaps, tap = s - chunk * ntaps;
+        src = tap * cin + chunk * 32 + (k & 31);
+      }
+      const float v = k < Ktot ? w[(long long)n * Ktot + src] * mult : 0.f;
       const _Float16 hi = (_Float16)v;
       o[t] = hi;
       o[4 + t] = (_Float16)(v - (float)hi);
@@ -226,8 +440,37 @@ static int launch_f16x3(ConvP &p, hipStream_t st) {
   return check_launch("conv_f16x3");
 }
 
+template <int BM, int BN, int WGM, int WGN>
+static int launch_f16x3_pipe(ConvP &p, hipStream_t st) {
+  const int tiles_m = cdiv(p.M, BM);
+  p.tiles_n = cdiv(p.Cout, BN);
+  const size_t lds = 2ull * 2 * (BM + BN) * PITCH2 * sizeof(_Float16);
+  auto kern = conv_f16x3_pipe_kernel<BM, BN, WGM, WGN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(conv_f16x3_pipe): %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int kpad4 = cdiv(p.Ktot, BKH) * BKH / 4;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(512), lds, st, p, kpad4);
+  return check_launch("conv_f16x3_pipe");
+}
+
+// f16x3 tile selection: 5: 256x256 / 8 waves, 6: 128x256 / 8 waves, else the 4-wave variants 0..3
+int select_variant_f16x3(int M, int Cout) {
+  if (Cout >= 224) {
+    const long long t256 = (long long)cdiv(M, 256) * cdiv(Cout, 256), t128 = (long long)cdiv(M, 128) * cdiv(Cout, 256);
+    if (t256 >= 384) return 5;
+    if (t128 >= 200) return 6;
+  }
+  return select_variant(M, Cout);
+}
+
 int launch_conv_f16x3(ConvP &p, hipStream_t st) {
-  switch (select_variant(p.M, p.Cout)) {
+  switch (select_variant_f16x3(p.M, p.Cout)) {
+    case 5: return launch_f16x3_pipe<256, 256, 2, 4>(p, st);
+    case 6: return launch_f16x3_pipe<128, 256, 2, 4>(p, st);
     case 0: return launch_f16x3<128, 128, 2, 2>(p, st);
     case 1: return launch_f16x3<64, 64, 2, 2>(p, st);
     case 2: return launch_f16x3<128, 32, 4, 1>(p, st);
@@ -239,10 +482,13 @@ int launch_conv_f16x3(ConvP &p, hipStream_t st) {
 
 using namespace mivos;
 
-extern "C" int mivos_pack_weights_f16x3(const float *w, void *out, int Cout, int Ktot, float mult, void *stream) {
-  if (!w || !out || Cout < 1 || Ktot < 4 || (Ktot & 3)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "pack_weights_f16x3: bad arguments");
+extern "C" int mivos_conv2d_variant_f16x3(int M, int Cout) { return select_variant_f16x3(M, Cout); }
+
+extern "C" int mivos_pack_weights_f16x3(const float *w, void *out, int Cout, int KH, int KW, int Cin, float mult, void *stream) {
+  const int Ktot = KH * KW * Cin;
+  if (!w || !out || Cout < 1 || Cin < 4 || (Cin & (Cin - 1)) || KH < 1 || KW < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "pack_weights_f16x3: bad arguments");
   const int Kpad = cdiv(Ktot, BKH) * BKH;
   hipLaunchKernelGGL(pack_weights_f16x3_kernel, dim3(cdiv((long long)Cout * (Kpad / 4), 256)), dim3(256), 0, (hipStream_t)stream,
-                     w, (_Float16 *)out, Cout, Ktot, Kpad, mult);
+                     w, (_Float16 *)out, Cout, Ktot, Kpad, mult, Cin, KH * KW);
   return check_launch("pack_weights_f16x3");
 }

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int bid = blockIdx.x;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
 
   // ---- loader state: thread -> (row lrow + 32 j, float4 k4 of the 32-wide chunk)

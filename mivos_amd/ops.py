@@ -17,7 +17,7 @@ _checked_devices = set()
 # fp32-MFMA rate); "f32": exact fp32 MFMA everywhere (the verification path).
 CONV_PRECISION = "f16x3"
 # bench.py sets this to a list to time every conv launch with HIP events on the launch stream:
-# entries (kernel variant, algorithmic FLOPs = 2*M*Cout*KH*KW*Cin, start event, end event)
+# entries (kernel variant [+10 for the f16x3 back-end], algorithmic FLOPs = 2*M*Cout*KH*KW*Cin, start event, end event)
 PROFILE = None
 
 
@@ -75,7 +75,7 @@ class ConvLayer:
             s = 14 - math.floor(math.log2(wmax)) if wmax > 0 else 0     # max |w * 2^s| in [2^14, 2^15)
             mult = 2.0 ** s
             w16 = torch.empty(self.cout * kpad * 4, dtype=torch.uint8, device=self.w.device)
-            check(_lib.load().mivos_pack_weights_f16x3(self.w.data_ptr(), w16.data_ptr(), self.cout, ktot, mult, _stream()))
+            check(_lib.load().mivos_pack_weights_f16x3(self.w.data_ptr(), w16.data_ptr(), self.cout, self.k, self.k, self.cin, mult, _stream()))
             base = self.scale if self.scale is not None else torch.ones(self.cout, dtype=torch.float32, device=self.w.device)
             self.w16, self.scale16 = w16, (base * (1.0 / mult)).contiguous()
         return self.w16, self.scale16
@@ -160,7 +160,8 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None):
     if PROFILE is not None:
         ev1.record()
         m = n * ho * wo
-        PROFILE.append((_lib.load().mivos_conv2d_variant(m, L.cout), 2.0 * m * L.cout * L.k * L.k * cin, ev0, ev1))
+        var = _lib.load().mivos_conv2d_variant_f16x3(m, L.cout) + 10 if d.precision == 1 else _lib.load().mivos_conv2d_variant(m, L.cout)
+        PROFILE.append((var, 2.0 * m * L.cout * L.k * L.k * cin, ev0, ev1))
     return (out, out2) if dual else out
 
 
