@@ -70,7 +70,7 @@ class StepTimer:
 def conv_roofline(samples):
     """Aggregate the HIP-event samples per kernel instantiation; the dominant one is the roofline kernel."""
     agg = {}
-    for variant, flops, e0, e1 in samples:
+    for variant, flops, e0, e1, _shape in samples:
         a = agg.setdefault(variant, [0.0, 0.0, 0])
         a[0] += flops
         a[1] += e0.elapsed_time(e1) * 1e-3
@@ -158,6 +158,15 @@ def main():
     if rank != 0:
         return
     roof, table = conv_roofline(timer.samples)
+    if os.environ.get("MIVOS_BENCH_SHAPES"):          # debug: per-shape conv time inside the timed region
+        agg = {}
+        for variant, flops, e0, e1, shape in timer.samples:
+            a = agg.setdefault((variant,) + shape, [0.0, 0.0, 0])
+            a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+        tot = sum(a[1] for a in agg.values())
+        for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+            print(f"# {VARIANT_NAMES[key[0]]:38s} M={key[1]:7d} Cin={key[2]:4d} Cout={key[3]:4d} k={key[4]} s={key[5]}  n={a[2]:4d} "
+                  f"avg {a[1] / a[2] * 1e6:8.1f} us  {a[0] / a[1] / 1e12:6.1f} TF/s  share {a[1] / tot * 100:5.1f}%", file=sys.stderr)
     out = dict(metric="propagated frames/sec, DAVIS-2017 480p multi-object", value=round(world * args.steps / elapsed, 3),
                unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",

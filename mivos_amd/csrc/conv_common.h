@@ -8,7 +8,7 @@ struct ConvP {
   const float *x, *w, *scale, *bias, *res;
   float *y, *y2;
   int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, split, relu_in, relu_out;
-  int log2Cin, M, Ktot, HoWo, tiles_n;
+  int log2Cin, M, Ktot, HoWo, tiles_n, vec_epi;
   long long x_ns, x_ps, y_ns, y_ps, y2_ns, y2_ps, r_ns, r_ps;
 };
 
@@ -30,6 +30,82 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   if (nwg < 16) return b;
   const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, pos = b >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+}
+
+// ---- epilogues shared by the implicit-GEMM kernels ----------------------------------------------------
+// acc tile layout (32x32 MFMA C/D): lane (n = lane&31, h = lane>>5), register r -> pixel row mfma32_row(r, lane).
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue_scalar(const f32x16 (&acc)[MT][NT], const ConvP &p, int m_base, int n_base, int lane) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n_base + j * 32 + (lane & 31);
+    if (n >= p.Cout) continue;
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float bi = p.bias ? p.bias[n] : 0.f;
+    float *dst;
+    long long d_ns, d_ps;
+    int dn;
+    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_ps = p.y_ps; dn = n; }
+    else { dst = p.y2; d_ns = p.y2_ns; d_ps = p.y2_ps; dn = n - p.split; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_base + i * 32 + mfma32_row(r, lane);
+        if (m >= p.M) continue;
+        const int img = m / p.HoWo, pix = m - img * p.HoWo;
+        float v = acc[i][j][r] * sc + bi;
+        if (p.res) v += p.res[(long long)img * p.r_ns + (long long)pix * p.r_ps + n];
+        if (p.relu_out) v = fmaxf(v, 0.f);
+        dst[(long long)img * d_ns + (long long)pix * d_ps + dn] = v;
+      }
+    }
+  }
+}
+
+// Vectorised epilogue: each 32x32 tile is transposed through a per-wave LDS scratch (32 x 36 floats) so
+// that a lane owns 4 consecutive CHANNELS of one pixel: residual loads and output stores become 16-byte
+// accesses, 8 lanes per 128-B line (the memory-bound 1x1 expansion convs were store-issue bound with one
+// dword per lane: 1.5 TB/s).  Needs Cout, split and all strides % 4 == 0 (p.vec_epi, checked on the host).
+constexpr int EPI_PITCH = 36;
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float *scratch, const ConvP &p, int m_base,
+                                             int n_base, int lane) {
+  const int prow0 = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n_base + j * 32 + c4;
+    const bool nok = n < p.Cout;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+    if (nok && p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + n);
+    if (nok && p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + n);
+    float *dst;
+    long long d_ns, d_ps;
+    int dn;
+    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_ps = p.y_ps; dn = n; }
+    else { dst = p.y2; d_ns = p.y2_ns; d_ps = p.y2_ps; dn = n - p.split; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scratch[mfma32_row(r, lane) * EPI_PITCH + (lane & 31)] = acc[i][j][r];
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int prow = ps * 8 + prow0;
+        const int m = m_base + i * 32 + prow;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(scratch + prow * EPI_PITCH + c4);
+        if (m < p.M && nok) {
+          const int img = m / p.HoWo, pix = m - img * p.HoWo;
+          v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
+          if (p.res) {
+            const f32x4 rr = *reinterpret_cast<const f32x4 *>(p.res + (long long)img * p.r_ns + (long long)pix * p.r_ps + n);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+          if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          *reinterpret_cast<f32x4 *>(dst + (long long)img * d_ns + (long long)pix * d_ps + dn) = v;
+        }
+      }
+    }
+  }
 }
 
 // fills ConvP from the public descriptor after validating it; returns a status code

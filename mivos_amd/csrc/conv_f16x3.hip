@@ -188,30 +188,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvP p, int kpad4) 
     }
   }
 
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wn * TN + j * 32 + (lane & 31);
-    if (n >= p.Cout) continue;
-    const float sc = p.scale ? p.scale[n] : 1.f;
-    const float bi = p.bias ? p.bias[n] : 0.f;
-    float *dst;
-    long long d_ns, d_ps;
-    int dn;
-    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_ps = p.y_ps; dn = n; }
-    else { dst = p.y2; d_ns = p.y2_ns; d_ps = p.y2_ps; dn = n - p.split; }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * TM + i * 32 + mfma32_row(r, lane);
-        if (m >= p.M) continue;
-        const int img = m / p.HoWo, pix = m - img * p.HoWo;
-        float v = acc[i][j][r] * sc + bi;
-        if (p.res) v += p.res[(long long)img * p.r_ns + (long long)pix * p.r_ps + n];
-        if (p.relu_out) v = fmaxf(v, 0.f);
-        dst[(long long)img * d_ns + (long long)pix * d_ps + dn] = v;
-      }
-    }
+  if (p.vec_epi) {
+    __syncthreads();   // LDS stages are dead: reuse them as per-wave transpose scratch
+    epilogue_vec<MT, NT>(acc, reinterpret_cast<float *>(smem_raw) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
+  } else {
+    epilogue_scalar<MT, NT>(acc, p, m0 + wm * TM, n0 + wn * TN, lane);
   }
 }
 
@@ -373,30 +354,11 @@ __global__ __launch_bounds__(512) void conv_f16x3_pipe_kernel(ConvP p, int kpad4
   }
   step(lds + ((nk - 1) & 1) * STAGE, nullptr, std::false_type{});
 
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wn * TN + j * 32 + (lane & 31);
-    if (n >= p.Cout) continue;
-    const float sc = p.scale ? p.scale[n] : 1.f;
-    const float bi = p.bias ? p.bias[n] : 0.f;
-    float *dst;
-    long long d_ns, d_ps;
-    int dn;
-    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_ps = p.y_ps; dn = n; }
-    else { dst = p.y2; d_ns = p.y2_ns; d_ps = p.y2_ps; dn = n - p.split; }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * TM + i * 32 + mfma32_row(r, lane);
-        if (m >= p.M) continue;
-        const int img = m / p.HoWo, pix = m - img * p.HoWo;
-        float v = acc[i][j][r] * sc + bi;
-        if (p.res) v += p.res[(long long)img * p.r_ns + (long long)pix * p.r_ps + n];
-        if (p.relu_out) v = fmaxf(v, 0.f);
-        dst[(long long)img * d_ns + (long long)pix * d_ps + dn] = v;
-      }
-    }
+  if (p.vec_epi) {
+    __syncthreads();   // LDS stages are dead: reuse them as per-wave transpose scratch
+    epilogue_vec<MT, NT>(acc, reinterpret_cast<float *>(smem_raw) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
+  } else {
+    epilogue_scalar<MT, NT>(acc, p, m0 + wm * TM, n0 + wn * TN, lane);
   }
 }
 

@@ -133,31 +133,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns channel (lane&31) of each n-tile, 16 pixel rows per (m-tile, n-tile)
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wn * TN + j * 32 + (lane & 31);
-    if (n >= p.Cout) continue;
-    const float sc = p.scale ? p.scale[n] : 1.f;
-    const float bi = p.bias ? p.bias[n] : 0.f;
-    float *dst;
-    long long d_ns, d_ps;
-    int dn;
-    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_ps = p.y_ps; dn = n; }
-    else { dst = p.y2; d_ns = p.y2_ns; d_ps = p.y2_ps; dn = n - p.split; }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * TM + i * 32 + mfma32_row(r, lane);
-        if (m >= p.M) continue;
-        const int img = m / p.HoWo, pix = m - img * p.HoWo;
-        float v = acc[i][j][r] * sc + bi;
-        if (p.res) v += p.res[(long long)img * p.r_ns + (long long)pix * p.r_ps + n];
-        if (p.relu_out) v = fmaxf(v, 0.f);
-        dst[(long long)img * d_ns + (long long)pix * d_ps + dn] = v;
-      }
-    }
+  // ---- epilogue (LDS stages are dead: reuse them as per-wave transpose scratch)
+  if (p.vec_epi) {
+    __syncthreads();
+    epilogue_vec<MT, NT>(acc, lds + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
+  } else {
+    epilogue_scalar<MT, NT>(acc, p, m0 + wm * TM, n0 + wn * TN, lane);
   }
 }
 
@@ -245,6 +226,9 @@ int conv_params_from_desc(const mivos_conv_desc *d, ConvP &p) {
   p.HoWo = d->Ho * d->Wo; p.M = d->N * p.HoWo; p.Ktot = d->KH * d->KW * d->Cin; p.tiles_n = 1;
   p.x_ns = d->x_nstride; p.x_ps = d->x_pstride; p.y_ns = d->y_nstride; p.y_ps = d->y_pstride;
   p.y2_ns = d->y2_nstride; p.y2_ps = d->y2_pstride; p.r_ns = d->res_nstride; p.r_ps = d->res_pstride;
+  auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
+  p.vec_epi = !(p.Cout & 3) && !(p.split & 3) && !((p.y_ns | p.y_ps) & 3) && al16(p.y) && al16(p.scale) && al16(p.bias) &&
+              (!dual || (!((p.y2_ns | p.y2_ps) & 3) && al16(p.y2))) && (!p.res || (!((p.r_ns | p.r_ps) & 3) && al16(p.res)));
   return MIVOS_OK;
 }
 }  // namespace mivos

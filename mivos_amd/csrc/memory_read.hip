@@ -9,8 +9,9 @@
 //     with the next tile's global loads in flight while the current one is multiplied;
 //   * 64 x v_mfma_f32_32x32x2_f32 give a 32x32 score tile; lane (j, h) owns 16 scores of query j;
 //   * scores above the query's running threshold tau are appended to a per-query LDS candidate buffer
-//     (packed 64-bit {orderable score, ~index}); when a buffer may overflow the owning wave compacts
-//     it to the exact top-k by an all-pairs rank and raises tau (wave-level, no workgroup barrier).
+//     (packed 64-bit {orderable score, ~index}; one LDS atomic per lane and half-tile); when a buffer may
+//     overflow the owning wave compacts it to the exact top-k with a wave-level radix select (ballot
+//     bisection of the k-th score) and raises tau (no workgroup barrier).
 //   The k best of every (object, chunk, query) go to the workspace.
 // Kernel 2 (memread_finalize): one wave per (object, query): merge the per-chunk lists to the exact
 //   top-k, exp(s - s_max)/sum in the reference's order, then gather the k value rows (2 KB each) in
@@ -42,35 +43,52 @@ __device__ __forceinline__ uint64_t pack_cand(float s, uint32_t idx) {
 __device__ __forceinline__ float cand_score(uint64_t c) { return ord2f((uint32_t)(c >> 32)); }
 __device__ __forceinline__ uint32_t cand_index(uint64_t c) { return 0xffffffffu - (uint32_t)c; }
 
-// Exact top-k of one query's candidate buffer, executed by the owning wave (all 64 lanes).
-// Leaves the survivors sorted (best first) in slots [0, min(n,k)), updates cnt / tau.
-// All-pairs rank: lane l owns entries l and l+64 and counts how many of the n entries beat them; the
-// entries are streamed as 16-byte LDS broadcasts (2 candidates per ds_read_b128).  Only the owning wave
-// touches a query's buffer, LDS ops of one wave execute in order, so no barrier is needed — the asm
-// statements only stop the compiler from caching LDS values across the wave-level hand-offs.
+// Exact top-k of one query's candidate buffer, executed by the owning wave (all 64 lanes; lane l owns
+// entries l and l+64).  Wave-level radix select: the k-th largest score is found by bisecting its 32
+// orderable bits MSB-first with two ballots per bit, survivors are compacted with ballot prefix sums
+// (order inside the buffer is irrelevant, the finalize kernel ranks).  Exact score ties at the threshold
+// are resolved toward the lower memory index.  Only the owning wave touches a query's buffer and the LDS
+// ops of one wave execute in order, so no barrier is needed — the asm statements only stop the compiler
+// from caching LDS values across the wave-level hand-offs.
 __device__ __forceinline__ void compact_query(uint64_t *buf, int *cnt, float *tau, int k, int lane) {
   asm volatile("" ::: "memory");
   const int n = *cnt;
+  if (n <= k) return;                                     // nothing to drop, threshold unchanged
   const uint64_t e0 = lane < n ? buf[lane] : 0ull;
   const uint64_t e1 = lane + 64 < n ? buf[lane + 64] : 0ull;
-  int r0 = 0, r1 = 0;
-  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-  const u64x2 *b2 = reinterpret_cast<const u64x2 *>(buf);
-#pragma unroll 4
-  for (int i = 0; i < n; i += 2) {
-    u64x2 c = b2[i >> 1];
-    if (i + 1 >= n) c.y = 0ull;
-    r0 += (c.x > e0) + (c.y > e0);
-    r1 += (c.x > e1) + (c.y > e1);
+  const uint32_t a0 = (uint32_t)(e0 >> 32), a1 = (uint32_t)(e1 >> 32);   // 0 = empty (below every valid score)
+  uint32_t prefix = 0;
+  int rem = k;
+#pragma unroll 1
+  for (int b = 31; b >= 0; --b) {
+    const uint32_t cand = prefix | (1u << b), msk = ~((1u << b) - 1u);
+    const int c = __popcll(__ballot((a0 & msk) == cand)) + __popcll(__ballot((a1 & msk) == cand));
+    if (c >= rem) prefix = cand; else rem -= c;
   }
+  // prefix = k-th largest score; rem = how many entries equal to it must be kept
+  const bool gt0 = a0 > prefix, gt1 = a1 > prefix;
+  bool eq0 = a0 == prefix, eq1 = a1 == prefix;
+  const int neq = __popcll(__ballot(eq0)) + __popcll(__ballot(eq1));
+  if (neq != rem) {                                        // rare: exact ties straddle the cut -> lowest indices win
+    const uint32_t l0 = (uint32_t)e0, l1 = (uint32_t)e1;   // ~index: larger = lower memory index
+    int r0 = 0, r1 = 0;
+    for (int i = 0; i < n; ++i) {
+      const uint64_t c = buf[i];
+      const bool ceq = (uint32_t)(c >> 32) == prefix;
+      r0 += ceq && (uint32_t)c > l0;
+      r1 += ceq && (uint32_t)c > l1;
+    }
+    eq0 = eq0 && r0 < rem;
+    eq1 = eq1 && r1 < rem;
+  }
+  const bool keep0 = gt0 || eq0, keep1 = gt1 || eq1;
+  const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int p0 = __popcll(m0 & below), p1 = __popcll(m0) + __popcll(m1 & below);
   asm volatile("" ::: "memory");
-  if (lane < n && r0 < k) buf[r0] = e0;
-  if (lane + 64 < n && r1 < k) buf[r1] = e1;
-  if (n >= k) {
-    if (lane < n && r0 == k - 1) *tau = cand_score(e0);
-    if (lane + 64 < n && r1 == k - 1) *tau = cand_score(e1);
-  }
-  if (lane == 0) *cnt = n < k ? n : k;
+  if (keep0) buf[p0] = e0;
+  if (keep1) buf[p1] = e1;
+  if (lane == 0) { *cnt = k; *tau = ord2f(prefix); }
   asm volatile("" ::: "memory");
 }
 
@@ -156,14 +174,22 @@ __global__ __launch_bounds__(256) void memread_select_kernel(const float *__rest
         }
         my_tau = tau[qslot];
       }
+      // one LDS atomic per lane and half-tile: reserve as many slots as this lane has passing scores
+      uint32_t passmask = 0;
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const int r = half * 8 + rr;
         const long long m = kb + mfma32_row(r, lane);
-        const float s = acc[r];
-        if (m < c1 && s > my_tau) {
-          const int pos = atomicAdd(cnt + qslot, 1);
-          cand[qslot * CAP + pos] = pack_cand(s, (uint32_t)m);
+        passmask |= (uint32_t)(m < c1 && acc[r] > my_tau) << rr;
+      }
+      if (passmask) {
+        int pos = atomicAdd(cnt + qslot, __popc(passmask));
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          if (passmask & (1u << rr)) {
+            const int r = half * 8 + rr;
+            cand[qslot * CAP + pos++] = pack_cand(acc[r], (uint32_t)(kb + mfma32_row(r, lane)));
+          }
         }
       }
     }
@@ -212,18 +238,15 @@ __global__ __launch_bounds__(64) void memread_finalize_kernel(const uint64_t *__
     rank[e] = 0;
   }
   __syncthreads();
-  if (n_split == 1) {  // already the sorted exact top-k
-    if (lane < top_k) sel[lane] = mine[0];
-  } else {
-    for (int i = 0; i < n; ++i) {
-      const uint64_t c = all[i];
+  // exact merge of the per-chunk survivor lists (unsorted): all-pairs rank, best first
+  for (int i = 0; i < n; ++i) {
+    const uint64_t c = all[i];
 #pragma unroll
-      for (int e = 0; e < MAX_SPLIT; ++e) rank[e] += (c > mine[e]) ? 1 : 0;
-    }
-#pragma unroll
-    for (int e = 0; e < MAX_SPLIT; ++e)
-      if (lane + 64 * e < n && mine[e] != 0ull && rank[e] < top_k) sel[rank[e]] = mine[e];
+    for (int e = 0; e < MAX_SPLIT; ++e) rank[e] += (c > mine[e]) ? 1 : 0;
   }
+#pragma unroll
+  for (int e = 0; e < MAX_SPLIT; ++e)
+    if (lane + 64 * e < n && mine[e] != 0ull && rank[e] < top_k) sel[rank[e]] = mine[e];
   __syncthreads();
   // softmax over the k survivors, max = best score (prop_net.py:55), sum in rank order
   const uint64_t c = lane < top_k ? sel[lane] : 0ull;
@@ -264,7 +287,9 @@ __global__ __launch_bounds__(64) void memread_finalize_kernel(const uint64_t *__
 struct SplitPlan { int n_split; long long chunk; };
 static SplitPlan plan_split(int n_obj, long long n_mem, int n_q) {
   const long long q_tiles = cdiv(n_q, QT), tiles = cdiv(n_mem, KT);
-  long long s = cdiv(384, q_tiles * n_obj);   // aim at >= ~1.5 workgroups per CU
+  // the 133 KB of LDS per workgroup allow one workgroup per CU: size the split so that the grid is one
+  // round of <= 256 workgroups (more chunks = more per-chunk survivors to select and merge)
+  long long s = 256 / (q_tiles * n_obj);
   if (s > MAX_SPLIT) s = MAX_SPLIT;
   if (s > tiles) s = tiles;
   if (s < 1) s = 1;

@@ -161,7 +161,7 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None):
         ev1.record()
         m = n * ho * wo
         var = _lib.load().mivos_conv2d_variant_f16x3(m, L.cout) + 10 if d.precision == 1 else _lib.load().mivos_conv2d_variant(m, L.cout)
-        PROFILE.append((var, 2.0 * m * L.cout * L.k * L.k * cin, ev0, ev1))
+        PROFILE.append((var, 2.0 * m * L.cout * L.k * L.k * cin, ev0, ev1, (m, cin, L.cout, L.k, L.stride)))
     return (out, out2) if dual else out
 
 
