@@ -36,7 +36,8 @@ VARIANT_NAMES = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<64,6
                  2: "conv_igemm_kernel<128,32,4,1>", 3: "conv_igemm_kernel<128,64,2,2>", 4: "conv_cout1_kernel",
                  10: "conv_f16x3_kernel<128,128,2,2>", 11: "conv_f16x3_kernel<64,64,2,2>", 12: "conv_f16x3_kernel<128,32,4,1>",
                  13: "conv_f16x3_kernel<128,64,2,2>", 14: "conv_cout1_kernel", 15: "conv_f16x3_pipe_kernel<256,256,2,4>",
-                 16: "conv_f16x3_pipe_kernel<128,256,2,4>"}
+                 16: "conv_f16x3_pipe_kernel<128,256,2,4>", 17: "conv_f16x3_pipe_kernel<128,128,4,2>",
+                 18: "conv_f16x3_pipe_kernel<64,256,2,4>"}
 
 
 class StepTimer:
@@ -97,7 +98,9 @@ def cpu_baseline(images, gt, k, top_k, mem_freq, engine_masks, frames):
     from oracle import stm_oracle as O
     from mivos_amd.util import synthetic
     from mivos_amd.util.tensor_util import compute_np_iou
-    torch.set_num_threads(os.cpu_count() or 1)
+    # oneDNN/OpenMP scale poorly past a few dozen threads on these small convolutions (256 threads on the
+    # 256-core host of the GPU box were 10x slower than 8 threads): use min(32, cores) and say so
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     sd, fsd = synthetic.make_prop_state(0), synthetic.make_fuse_state(0)
     core = O.OracleCore(sd, fsd, images[:, :frames + 1], k, mem_freq=mem_freq, top_k=top_k)
     t0 = time.perf_counter()
@@ -119,7 +122,7 @@ def main():
     ap.add_argument("--width", type=int, default=854)
     ap.add_argument("--top-k", type=int, default=50)
     ap.add_argument("--mem-freq", type=int, default=5)
-    ap.add_argument("--cpu-frames", type=int, default=3, help="propagated frames of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=2, help="propagated frames of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--profile-every", type=int, default=8, help="HIP-event sample every n-th timed step (0 = off)")
     args = ap.parse_args()
 

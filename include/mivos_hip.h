@@ -90,7 +90,8 @@ int mivos_pack_weights_f16x3(const float *w, void *out, int Cout, int KH, int KW
 /* Which kernel instantiation mivos_conv2d_fused picks for M = N*Ho*Wo output pixels and Cout channels
  * (0: 128x128 tile, 1: 64x64, 2: 128x32, 3: 128x64, 4: Cout==1 dot product) — for profilers/benchmarks. */
 int mivos_conv2d_variant(int M, int Cout);
-/* Same for precision 1 (f16x3): additionally 5: 256x256 tile / 8 waves pipelined, 6: 128x256 / 8 waves. */
+/* Same for precision 1 (f16x3): additionally 5: 256x256 tile / 8 waves pipelined, 6: 128x256 / 8 waves,
+ * 7: 128x128 / 8 waves. */
 int mivos_conv2d_variant_f16x3(int M, int Cout);
 
 /* MaxPool2d(3, stride 2, pad 1) on NHWC (mod_resnet.py:121 / torchvision stem). C % 4 == 0. */

@@ -419,13 +419,17 @@ static int launch_f16x3_pipe(ConvP &p, hipStream_t st) {
   return check_launch("conv_f16x3_pipe");
 }
 
-// f16x3 tile selection: 5: 256x256 / 8 waves, 6: 128x256 / 8 waves, else the 4-wave variants 0..3
+// f16x3 tile selection: 5: 256x256 / 8 waves, 6: 128x256 / 8 waves, 7: 128x128 / 8 waves, 8: 64x256 / 8 waves
+// (all pipelined),
+// else the 4-wave variants 0..3
 int select_variant_f16x3(int M, int Cout) {
   if (Cout >= 224) {
     const long long t256 = (long long)cdiv(M, 256) * cdiv(Cout, 256), t128 = (long long)cdiv(M, 128) * cdiv(Cout, 256);
     if (t256 >= 384) return 5;
     if (t128 >= 200) return 6;
+    if (Cout % 256 == 0 && (long long)cdiv(M, 64) * cdiv(Cout, 256) >= 200) return 8;
   }
+  if (Cout >= 96 && (long long)cdiv(M, 128) * cdiv(Cout, 128) >= 200) return 7;
   return select_variant(M, Cout);
 }
 
@@ -433,6 +437,8 @@ int launch_conv_f16x3(ConvP &p, hipStream_t st) {
   switch (select_variant_f16x3(p.M, p.Cout)) {
     case 5: return launch_f16x3_pipe<256, 256, 2, 4>(p, st);
     case 6: return launch_f16x3_pipe<128, 256, 2, 4>(p, st);
+    case 7: return launch_f16x3_pipe<128, 128, 4, 2>(p, st);
+    case 8: return launch_f16x3_pipe<64, 256, 2, 4>(p, st);
     case 0: return launch_f16x3<128, 128, 2, 2>(p, st);
     case 1: return launch_f16x3<64, 64, 2, 2>(p, st);
     case 2: return launch_f16x3<128, 32, 4, 1>(p, st);
