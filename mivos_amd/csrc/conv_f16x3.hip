@@ -362,6 +362,167 @@ __global__ __launch_bounds__(512) void conv_f16x3_pipe_kernel(ConvP p, int kpad4
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Direct 3x3 / stride 1 / pad 1 convolution with 32 output channels (FusionNet body, fusion_net.py:12-27).
+// As an implicit GEMM these layers (N = 32, K = 144/288, 2 M pixels at 480p x 5 objects) are staging-bound:
+// every input element is converted and written to LDS nine times for 32*3 MFMA MACs each.  Here a
+// workgroup (8 waves) owns an 8-row x 32-column output tile: the 10 x 34 input patch is split to fp16
+// hi/lo ONCE into LDS, all 9 taps read their A fragments from it at shifted addresses (80-byte pixel pitch,
+// conflict-free), and the packed weights of all taps are LDS-resident.  Traffic per layer = one read of the
+// input + one write of the output (+ residual): HBM-bound.
+template <int CIN>
+__global__ __launch_bounds__(512) void conv3x3_n32_direct_kernel(ConvP p, int kpad4, int tiles_x, int tiles_y, int n_tiles) {
+  constexpr int TR = 8, TC = 32, PR = TR + 2, PC = TC + 2;
+  constexpr int PPX = CIN + 8;                 // halves per patch pixel (pitch 80 B / 48 B)
+  constexpr int PW = CIN + 8;                  // halves per weight row
+  constexpr int KH16 = CIN / 16;               // MFMA k-blocks per tap
+  constexpr int NLD = (PR * PC * (CIN / 4) + 511) / 512;     // float4 patch loads per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int PATCH = 2 * PR * PC * PPX;                      // halves per patch buffer: hi image | lo image
+  _Float16 *P0 = reinterpret_cast<_Float16 *>(smem_raw);        // two patch buffers (double buffered)
+  _Float16 *Wh = P0 + 2 * PATCH;                                // weights hi [9][32][PW]
+  _Float16 *Wl = Wh + 9 * 32 * PW;                              // weights lo
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // ---- weights once per (persistent) workgroup: packed [32][kpad4][hi0..3 | lo0..3] -> [tap][n][c] hi / lo
+  for (int e = tid; e < 32 * 9 * CIN / 4; e += 512) {
+    const int n = e / (9 * CIN / 4), q = e - n * (9 * CIN / 4);
+    const f32x4 v = reinterpret_cast<const f32x4 *>(p.w)[(long long)n * kpad4 + q];
+    const int k = 4 * q, tap = k / CIN, c = k - tap * CIN;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 hh, ll;
+    hh.x = v.x; hh.y = v.y; ll.x = v.z; ll.y = v.w;
+    *reinterpret_cast<f32x2 *>(Wh + (tap * 32 + n) * PW + c) = hh;
+    *reinterpret_cast<f32x2 *>(Wl + (tap * 32 + n) * PW + c) = ll;
+  }
+  const float relu_floor = p.relu_in ? 0.f : -INFINITY;
+  const int i = lane & 31, h = lane >> 5;
+  f32x4 pre[NLD];
+  // all patch loads of a tile are issued back to back (registers), converted + written later
+  auto load_patch = [&](int tile) {
+    int t = tile;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int img = t / tiles_y;
+    const float *xb = p.x + (long long)img * p.x_ns;
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+      const int e = tid + 512 * l;
+      const int px = e / (CIN / 4), c4 = e - px * (CIN / 4);
+      const int pr = px / PC, pc = px - pr * PC;
+      const int iy = ty * TR + pr - 1, ix = tx * TC + pc - 1;
+      const bool ok = e < PR * PC * (CIN / 4) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const long long off = ok ? ((long long)iy * p.W + ix) * p.x_ps + 4 * c4 : 0ll;
+      f32x4 v = *reinterpret_cast<const f32x4 *>(xb + off);
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      pre[l] = v;
+    }
+  };
+  auto write_patch = [&](_Float16 *Ph) {
+    _Float16 *Pl = Ph + PR * PC * PPX;
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+      const int e = tid + 512 * l;
+      if (e < PR * PC * (CIN / 4)) {
+        const int px = e / (CIN / 4), c4 = e - px * (CIN / 4);
+        f32x4 v = pre[l];
+        v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+        h4 hi, lo;
+        hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
+        lo.x = (_Float16)(v.x - (float)hi.x); lo.y = (_Float16)(v.y - (float)hi.y);
+        lo.z = (_Float16)(v.z - (float)hi.z); lo.w = (_Float16)(v.w - (float)hi.w);
+        *reinterpret_cast<h4 *>(Ph + px * PPX + 4 * c4) = hi;
+        *reinterpret_cast<h4 *>(Pl + px * PPX + 4 * c4) = lo;
+      }
+    }
+  };
+
+  // software pipeline over the tiles of this workgroup: while tile t is multiplied out of patch buffer
+  // t&1, tile t+1 (loaded into registers during tile t-1) is converted into the other buffer and the loads of
+  // tile t+2 are issued: one barrier per tile, every global load has a full tile of time to land.
+  int tile = blockIdx.x;
+  if (tile < n_tiles) { load_patch(tile); write_patch(P0); }
+  if (tile + (int)gridDim.x < n_tiles) load_patch(tile + gridDim.x);
+  __syncthreads();
+  for (int it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
+    const _Float16 *Ph = P0 + (it & 1) * PATCH, *Pl = Ph + PR * PC * PPX;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tap = kh * 3 + kw;
+        const int aoff = ((wave + kh) * PC + i + kw) * PPX + 8 * h;
+        const int boff = (tap * 32 + i) * PW + 8 * h;
+#pragma unroll
+        for (int kb = 0; kb < KH16; ++kb) {
+          const h8 ah = *reinterpret_cast<const h8 *>(Ph + aoff + 16 * kb);
+          const h8 al = *reinterpret_cast<const h8 *>(Pl + aoff + 16 * kb);
+          const h8 bh = *reinterpret_cast<const h8 *>(Wh + boff + 16 * kb);
+          const h8 bl = *reinterpret_cast<const h8 *>(Wl + boff + 16 * kb);
+          // weights are the MFMA "A" operand here: D[channel][pixel], so a lane ends up with 4 consecutive
+          // CHANNELS of one pixel per register quad -> 16-byte residual loads / stores
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc, 0, 0, 0);
+        }
+      }
+    }
+    // epilogue: lane = pixel (column x0 + lane&31), registers 4g..4g+3 = channels 8g + 4h .. +3
+    int t = tile;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int img = t / tiles_y;
+    const int y = ty * TR + wave;
+    const int x = tx * TC + i;
+    if (y < p.H && x < p.W) {
+      const long long pix = (long long)y * p.W + x;
+      const float *rp = p.res ? p.res + (long long)img * p.r_ns + pix * p.r_ps : nullptr;
+      float *yp = p.y + (long long)img * p.y_ns + pix * p.y_ps;
+      f32x4 out[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 8 * g + 4 * h;
+        const f32x4 s4 = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 b4 = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 v;
+        v.x = acc[4 * g] * s4.x + b4.x; v.y = acc[4 * g + 1] * s4.y + b4.y;
+        v.z = acc[4 * g + 2] * s4.z + b4.z; v.w = acc[4 * g + 3] * s4.w + b4.w;
+        if (rp) { const f32x4 r4 = *reinterpret_cast<const f32x4 *>(rp + c); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+        if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        out[g] = v;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(yp + 8 * g + 4 * h) = out[g];
+    }
+    if (tile + (int)gridDim.x < n_tiles) write_patch(P0 + ((it + 1) & 1) * PATCH);
+    if (tile + 2 * (int)gridDim.x < n_tiles) load_patch(tile + 2 * gridDim.x);
+    __syncthreads();
+  }
+}
+
+template <int CIN>
+static int launch_n32_direct(ConvP &p, hipStream_t st) {
+  const int tiles_x = cdiv(p.W, 32), tiles_y = cdiv(p.H, 8);
+  const size_t lds = (2ull * 2 * 10 * 34 * (CIN + 8) + 2ull * 9 * 32 * (CIN + 8)) * sizeof(_Float16);
+  auto kern = conv3x3_n32_direct_kernel<CIN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(conv3x3_n32_direct): %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int kpad4 = cdiv(p.Ktot, BKH) * BKH / 4;
+  const int n_tiles = tiles_x * tiles_y * p.N;
+  const int grid = n_tiles < 256 ? n_tiles : 256;            // persistent: one workgroup per CU walks the tiles
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, kpad4, tiles_x, tiles_y, n_tiles);
+  return check_launch("conv3x3_n32_direct");
+}
+
 __global__ void pack_weights_f16x3_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, int Cout, int Ktot,
                                           int Kpad, float mult, int cin, int ntaps) {
   const bool taps_inner = (cin & 31) == 0;
@@ -434,6 +595,8 @@ int select_variant_f16x3(int M, int Cout) {
 }
 
 int launch_conv_f16x3(ConvP &p, hipStream_t st) {
+  if (p.vec_epi && p.Cout == 32 && p.split == 32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && (p.Cin == 16 || p.Cin == 32))
+    return p.Cin == 16 ? launch_n32_direct<16>(p, st) : launch_n32_direct<32>(p, st);
   switch (select_variant_f16x3(p.M, p.Cout)) {
     case 5: return launch_f16x3_pipe<256, 256, 2, 4>(p, st);
     case 6: return launch_f16x3_pipe<128, 256, 2, 4>(p, st);

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 // LPP lanes share one output pixel; per tap they read the pixel's Cin floats as LPP consecutive float4
 // (one full line per 8 lanes), 8 rounds, then a butterfly over the LPP lanes.  Weights (<= 9*256
 // floats) live in LDS.
-template <int LPP>
+template <int LPP, int QPL>   // LPP lanes per pixel, QPL float4 per lane and tap: Cin = 4 * LPP * QPL
 __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   for (int i = threadIdx.x; i < p.Ktot; i += 256) wl[i] = p.w[i];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvP p) {
       const f32x4 *px = reinterpret_cast<const f32x4 *>(xb + ((long long)ih * p.W + iw) * p.x_ps) + sub;
       const f32x4 *pw = reinterpret_cast<const f32x4 *>(wl + (kh * p.KW + kw) * p.Cin) + sub;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < QPL; ++q) {
         f32x4 v = px[q * LPP], w4 = pw[q * LPP];
         if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         acc = fmaf(v.x, w4.x, acc); acc = fmaf(v.y, w4.y, acc);
@@ -242,14 +242,13 @@ extern "C" int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream) {
 
   if (p.Cout == 1) {
     if (p.Cin % 32) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: Cout=1 path needs Cin %% 32 == 0");
-    const int lpp = p.Cin / 32;
     const size_t lds = (size_t)p.Ktot * sizeof(float);
-    const int blocks = cdiv((long long)p.M * lpp, 256);
-    switch (lpp) {
-      case 1: hipLaunchKernelGGL(conv_cout1_kernel<1>, dim3(blocks), dim3(256), lds, st, p); break;
-      case 2: hipLaunchKernelGGL(conv_cout1_kernel<2>, dim3(blocks), dim3(256), lds, st, p); break;
-      case 4: hipLaunchKernelGGL(conv_cout1_kernel<4>, dim3(blocks), dim3(256), lds, st, p); break;
-      case 8: hipLaunchKernelGGL(conv_cout1_kernel<8>, dim3(blocks), dim3(256), lds, st, p); break;
+    const int blocks = cdiv((long long)p.M * 8, 256);         // 8 lanes per pixel: one 128-B line per tap
+    switch (p.Cin) {
+      case 32: hipLaunchKernelGGL((conv_cout1_kernel<8, 1>), dim3(blocks), dim3(256), lds, st, p); break;
+      case 64: hipLaunchKernelGGL((conv_cout1_kernel<8, 2>), dim3(blocks), dim3(256), lds, st, p); break;
+      case 128: hipLaunchKernelGGL((conv_cout1_kernel<8, 4>), dim3(blocks), dim3(256), lds, st, p); break;
+      case 256: hipLaunchKernelGGL((conv_cout1_kernel<8, 8>), dim3(blocks), dim3(256), lds, st, p); break;
       default: return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: Cout=1 path supports Cin in {32,64,128,256}");
     }
     return check_launch("conv_cout1");
