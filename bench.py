@@ -92,9 +92,12 @@ def conv_roofline(samples):
     return roof, table
 
 
-def cpu_baseline(images, gt, k, top_k, mem_freq, engine_masks, frames):
+def cpu_baseline(images, gt, k, top_k, mem_freq, engine_masks, frames, with_fp64=True):
     """The CPU oracle (restatement of the reference, oracle/stm_oracle.py) on a bounded sample of the same
-    workload: the first `frames` propagated frames of the first interaction."""
+    workload: the first `frames` propagated frames of the first interaction.  Parity is reported three ways:
+    engine vs the fp32 oracle, and - because the algorithm is closed-loop and discontinuous (argmax / top-k
+    on an untrained network) - both of them against an fp64 run of the same oracle, which is the
+    noise floor any fp32 implementation of the reference has on this clip."""
     from oracle import stm_oracle as O
     from mivos_amd.util import synthetic
     from mivos_amd.util.tensor_util import compute_np_iou
@@ -106,10 +109,20 @@ def cpu_baseline(images, gt, k, top_k, mem_freq, engine_masks, frames):
     t0 = time.perf_counter()
     ref = core.interact(gt[0], 0)
     dt = time.perf_counter() - t0
-    ious = [float(compute_np_iou(engine_masks[1:frames + 1] == j, ref[1:] == j)) for j in range(1, k + 1)]
+
+    def miou(a, b):
+        return round(float(sum(compute_np_iou(a == j, b == j) for j in range(1, k + 1)) / k), 6)
+
+    eng = engine_masks[:frames + 1]
+    parity = dict(frames=frames, mean_iou_engine_vs_ref_fp32=miou(eng[1:], ref[1:]),
+                  mismatching_pixel_fraction=round(float((eng[1:] != ref[1:]).mean()), 6))
+    if with_fp64:
+        c64 = O.OracleCore(sd, fsd, images[:, :frames + 1], k, mem_freq=mem_freq, top_k=top_k, dtype=torch.float64)
+        r64 = c64.interact(gt[0], 0)
+        parity.update(mean_iou_ref_fp32_vs_ref_fp64=miou(ref[1:], r64[1:]), mean_iou_engine_vs_ref_fp64=miou(eng[1:], r64[1:]))
     return dict(value=round(frames / dt, 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"first {frames} propagated frames of the same clip ({k} objects, no fusion), oracle/stm_oracle.py on PyTorch-CPU fp32",
-                seconds=round(dt, 2)), dict(mean_iou_vs_oracle=round(sum(ious) / len(ious), 6), frames=frames)
+                seconds=round(dt, 2)), parity
 
 
 def main():

@@ -15,6 +15,8 @@
 // stage (A_hi, A_lo, B_hi, B_lo; K contiguous, 72-half pitch => conflict-free ds_read_b128 fragment reads,
 // one read = the 8 halves a lane feeds to one MFMA).  One LDS stage + register prefetch of the next stage
 // (two barriers per 64-deep step); two workgroups per CU overlap each other's barrier/convert phases.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "conv_common.h"
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvP p, int kpad4) 
 constexpr int BK2 = 32;     // k per stage
 constexpr int PITCH2 = 40;  // halves per LDS row (32 + 8 pad = 80 B, conflict-free b128 fragment reads)
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int ABL = 0>   // ABL: ablation switch for profiling builds only
 __global__ __launch_bounds__(512) void conv_f16x3_pipe_kernel(ConvP p, int kpad4) {
   static_assert(WGM * WGN == 8, "8 waves per workgroup");
   constexpr int TM = BM / WGM, TN = BN / WGN;
@@ -264,30 +266,52 @@ __global__ __launch_bounds__(512) void conv_f16x3_pipe_kernel(ConvP p, int kpad4
   // Branch-free loaders (the main loop must stay ONE basic block so that the scheduler can put the
   // staging VALU / LDS writes / global loads in the shadow of the MFMAs): invalid taps / rows load from
   // the tensor base and are zeroed by a select, steps past the end re-load the last step.
-  auto gload = [&](int k0) {
+  // Loads are issued PER STAGING PASS, right after the pass that frees their registers (see step()):
+  // every load then has a whole K step (~3000 cycles) to land.  (Issuing them at the end of the step
+  // left ~300 cycles before the first use: ablation = 2x slower than with the loads removed.)
+  int ld_kh = 0, ld_kw = 0, ld_c = 0, ld_k0 = 0;
+  bool ld_kok = true;
+  auto gload_setup = [&](int k0) {
     k0 = k0 < k_last ? k0 : k_last;
-    int tap, c;
-    if (uniform_tap) { decode_k(k0, p.Cin, p.log2Cin, ntaps, true, tap, c); c += 4 * k4; }   // wave-uniform tap
-    else decode_k(k0 + 4 * k4, p.Cin, p.log2Cin, ntaps, false, tap, c);
-    const bool kok = k0 + 4 * k4 < p.Ktot;
-    int kh, kw;
-    if (p.KW == 1) { kh = tap; kw = 0; }
-    else if (p.KW == 3) { kh = tap / 3; kw = tap - 3 * kh; }
-    else { kh = tap / p.KW; kw = tap - p.KW * kh; }
-#pragma unroll
-    for (int j = 0; j < A_LD; ++j) {
-      const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
-      const bool ok = kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      const long long off = ok ? ((long long)ih * p.W + iw) * p.x_ps + c : 0ll;
+    int tap;
+    if (uniform_tap) { decode_k(k0, p.Cin, p.log2Cin, ntaps, true, tap, ld_c); ld_c += 4 * k4; }   // wave-uniform tap
+    else decode_k(k0 + 4 * k4, p.Cin, p.log2Cin, ntaps, false, tap, ld_c);
+    ld_kok = k0 + 4 * k4 < p.Ktot;
+    if (p.KW == 1) { ld_kh = tap; ld_kw = 0; }
+    else if (p.KW == 3) { ld_kh = tap / 3; ld_kw = tap - 3 * ld_kh; }
+    else { ld_kh = tap / p.KW; ld_kw = tap - p.KW * ld_kh; }
+    ld_k0 = k0;
+  };
+  auto gload_pass = [&](int s) {
+    if (ABL == 1) {   // no global loads
+      if (s < A_LD) ra[s < A_LD ? s : 0] = f32x4{1.f, 2.f, 3.f, 4.f};
+      if (s < B_LD) rb[s < B_LD ? s : 0] = f32x4{1.f, 2.f, 3.f, 4.f};
+      return;
+    }
+    if (s < A_LD) {
+      const int j = s < A_LD ? s : 0;
+      const int ih = a_ih0[j] + ld_kh, iw = a_iw0[j] + ld_kw;
+      const bool ok = ld_kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      long long off = ok ? ((long long)ih * p.W + iw) * p.x_ps + ld_c : 0ll;
+      if (ABL == 4) off = (off & 0xfff);          // all loads from one hot 16 KB window (cache-hit ablation)
+      if (ABL == 5) off = ((long long)(m0 + lrow + RP * j) * p.Ktot + ld_k0) % ((long long)p.M * p.x_ps - 64) & ~3ll;   // streaming, no re-reads
       f32x4 v = *reinterpret_cast<const f32x4 *>(a_base[j] + off);
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
       ra[j] = v;
     }
+    if (s < B_LD) {
+      const int j = s < B_LD ? s : 0;
+      rb[j] = b_ptr[j][ABL == 4 ? 0 : (ld_k0 >> 2)];
+    }
+  };
+  auto gload = [&](int k0) {
+    gload_setup(k0);
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) rb[j] = b_ptr[j][k0 >> 2];
+    for (int s = 0; s < NSEG; ++s) gload_pass(s);
   };
   // convert + write one staging pass (A pass s and B pass s) of the prefetched registers into stage `st`
   auto lwrite_seg = [&](_Float16 *st, int s) {
+    if (ABL == 2) return;   // no conversion / LDS writes
     if (s < A_LD) {
       f32x4 v = ra[s];
       v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
@@ -333,12 +357,12 @@ __global__ __launch_bounds__(512) void conv_f16x3_pipe_kernel(ConvP p, int kpad4
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
-        if (STAGE_NEXT && kk * MT + i < NSEG) lwrite_seg(nxt, kk * MT + i);
+        if (STAGE_NEXT && kk * MT + i < NSEG) { lwrite_seg(nxt, kk * MT + i); gload_pass(kk * MT + i); }
       }
     }
     if (STAGE_NEXT) {
 #pragma unroll
-      for (int s = 2 * MT; s < NSEG; ++s) lwrite_seg(nxt, s);
+      for (int s = 2 * MT; s < NSEG; ++s) { lwrite_seg(nxt, s); gload_pass(s); }
     }
   };
 
@@ -348,11 +372,20 @@ __global__ __launch_bounds__(512) void conv_f16x3_pipe_kernel(ConvP p, int kpad4
   gload(BK2);
   __syncthreads();
   for (int kt = 0; kt + 1 < nk; ++kt) {
+    gload_setup((kt + 2) * BK2);          // addresses of the stage whose loads are issued inside step()
     step(lds + (kt & 1) * STAGE, lds + ((kt + 1) & 1) * STAGE, std::true_type{});
-    gload((kt + 2) * BK2);
     __syncthreads();
   }
   step(lds + ((nk - 1) & 1) * STAGE, nullptr, std::false_type{});
+  if (ABL == 3) {   // no epilogue (keep the accumulators alive)
+    float t = 0.f;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) t += acc[a][b][0];
+    if (t == 12345.678f) p.y[0] = t;
+    return;
+  }
 
   if (p.vec_epi) {
     __syncthreads();   // LDS stages are dead: reuse them as per-wave transpose scratch
@@ -563,12 +596,12 @@ static int launch_f16x3(ConvP &p, hipStream_t st) {
   return check_launch("conv_f16x3");
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int ABL = 0>
 static int launch_f16x3_pipe(ConvP &p, hipStream_t st) {
   const int tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.Cout, BN);
   const size_t lds = 2ull * 2 * (BM + BN) * PITCH2 * sizeof(_Float16);
-  auto kern = conv_f16x3_pipe_kernel<BM, BN, WGM, WGN>;
+  auto kern = conv_f16x3_pipe_kernel<BM, BN, WGM, WGN, ABL>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -598,7 +631,14 @@ int launch_conv_f16x3(ConvP &p, hipStream_t st) {
   if (p.vec_epi && p.Cout == 32 && p.split == 32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && (p.Cin == 16 || p.Cin == 32))
     return p.Cin == 16 ? launch_n32_direct<16>(p, st) : launch_n32_direct<32>(p, st);
   switch (select_variant_f16x3(p.M, p.Cout)) {
-    case 5: return launch_f16x3_pipe<256, 256, 2, 4>(p, st);
+    case 5: {
+      static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;   // profiling only
+      if (abl == 1) return launch_f16x3_pipe<256, 256, 2, 4, 1>(p, st);
+      if (abl == 2) return launch_f16x3_pipe<256, 256, 2, 4, 2>(p, st);
+      if (abl == 3) return launch_f16x3_pipe<256, 256, 2, 4, 3>(p, st);
+      if (abl == 4) return launch_f16x3_pipe<256, 256, 2, 4, 4>(p, st);
+      return launch_f16x3_pipe<256, 256, 2, 4>(p, st);
+    }
     case 6: return launch_f16x3_pipe<128, 256, 2, 4>(p, st);
     case 7: return launch_f16x3_pipe<128, 128, 4, 2>(p, st);
     case 8: return launch_f16x3_pipe<64, 256, 2, 4>(p, st);

@@ -8,7 +8,11 @@
 //     by the 4 waves; row pitch 132 floats => the ds_read_b128 fragment reads are bank-conflict-free)
 //     with the next tile's global loads in flight while the current one is multiplied;
 //   * 64 x v_mfma_f32_32x32x2_f32 give a 32x32 score tile; lane (j, h) owns 16 scores of query j;
-//   * scores above the query's running threshold tau are appended to a per-query LDS candidate buffer
+//   * scores above the query's running threshold tau are appended to a per-query candidate buffer that
+//     lives in GLOBAL memory (L2-resident workspace; counters and thresholds stay in LDS): with the buffers
+//     in LDS (133 KB) only one workgroup fit per CU and every barrier, LDS round trip and compaction stalled
+//     the only wave of its SIMD (affinity MFMA 15 % busy); now LDS is 18 KB, 3 workgroups share a CU and
+//     their MFMA / selection phases overlap
 //     (packed 64-bit {orderable score, ~index}; one LDS atomic per lane and half-tile); when a buffer may
 //     overflow the owning wave compacts it to the exact top-k with a wave-level radix select (ballot
 //     bisection of the k-th score) and raises tau (no workgroup barrier).
@@ -17,6 +21,8 @@
 //   top-k, exp(s - s_max)/sum in the reference's order, then gather the k value rows (2 KB each) in
 //   ascending memory index — the order in which the reference's dense bmm meets its non-zeros.
 // Ties: the lower memory index wins (torch.topk leaves ties unspecified).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mivos {
@@ -25,7 +31,7 @@ constexpr int CK = 128, CV = 512;
 constexpr int QT = 128;     // queries per workgroup
 constexpr int KT = 32;      // memory positions per tile
 constexpr int KLD = 132;    // LDS pitch of a key row (floats)
-constexpr int CAP = 112;    // candidate slots per query
+constexpr int CAP = 256;    // candidate slots per query (global memory)
 constexpr int CAP_TRIGGER = CAP - 16;   // a half-tile adds at most 16 candidates per query
 constexpr int MAX_SPLIT = 8;
 constexpr int MAX_TOPK = 64;
@@ -50,57 +56,82 @@ __device__ __forceinline__ uint32_t cand_index(uint64_t c) { return 0xffffffffu 
 // are resolved toward the lower memory index.  Only the owning wave touches a query's buffer and the LDS
 // ops of one wave execute in order, so no barrier is needed — the asm statements only stop the compiler
 // from caching LDS values across the wave-level hand-offs.
-__device__ __forceinline__ void compact_query(uint64_t *buf, int *cnt, float *tau, int k, int lane) {
-  asm volatile("" ::: "memory");
+__device__ __forceinline__ uint64_t ld_cand(const uint64_t *p) {
+  // candidates were appended with plain stores by lanes of THIS wave: read them back through L2 (sc1),
+  // never from a possibly stale L1 line
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// EPL entries per lane (CAP = 64 * EPL).  Returns the survivors in e[] with keep flags; when WRITE_BACK they
+// are also compacted in place.
+constexpr int EPL = CAP / 64;
+template <bool WRITE_BACK>
+__device__ __forceinline__ void compact_query(uint64_t *buf, int *cnt, float *tau, int k, int lane, uint64_t (&e)[EPL],
+                                              bool (&keep)[EPL]) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's appends have reached L2
   const int n = *cnt;
+  uint32_t a[EPL];
+#pragma unroll
+  for (int t = 0; t < EPL; ++t) {
+    keep[t] = lane + 64 * t < n;
+    e[t] = keep[t] ? ld_cand(buf + lane + 64 * t) : 0ull;
+    a[t] = (uint32_t)(e[t] >> 32);                        // 0 = empty (below every valid score)
+  }
   if (n <= k) return;                                     // nothing to drop, threshold unchanged
-  const uint64_t e0 = lane < n ? buf[lane] : 0ull;
-  const uint64_t e1 = lane + 64 < n ? buf[lane + 64] : 0ull;
-  const uint32_t a0 = (uint32_t)(e0 >> 32), a1 = (uint32_t)(e1 >> 32);   // 0 = empty (below every valid score)
   uint32_t prefix = 0;
   int rem = k;
 #pragma unroll 1
   for (int b = 31; b >= 0; --b) {
     const uint32_t cand = prefix | (1u << b), msk = ~((1u << b) - 1u);
-    const int c = __popcll(__ballot((a0 & msk) == cand)) + __popcll(__ballot((a1 & msk) == cand));
+    int c = 0;
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) c += __popcll(__ballot((a[t] & msk) == cand));
     if (c >= rem) prefix = cand; else rem -= c;
   }
   // prefix = k-th largest score; rem = how many entries equal to it must be kept
-  const bool gt0 = a0 > prefix, gt1 = a1 > prefix;
-  bool eq0 = a0 == prefix, eq1 = a1 == prefix;
-  const int neq = __popcll(__ballot(eq0)) + __popcll(__ballot(eq1));
+  bool eq[EPL];
+  int neq = 0;
+#pragma unroll
+  for (int t = 0; t < EPL; ++t) { eq[t] = a[t] == prefix; neq += __popcll(__ballot(eq[t])); }
   if (neq != rem) {                                        // rare: exact ties straddle the cut -> lowest indices win
-    const uint32_t l0 = (uint32_t)e0, l1 = (uint32_t)e1;   // ~index: larger = lower memory index
-    int r0 = 0, r1 = 0;
+    int r[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) r[t] = 0;
     for (int i = 0; i < n; ++i) {
-      const uint64_t c = buf[i];
+      const uint64_t c = ld_cand(buf + i);
       const bool ceq = (uint32_t)(c >> 32) == prefix;
-      r0 += ceq && (uint32_t)c > l0;
-      r1 += ceq && (uint32_t)c > l1;
+#pragma unroll
+      for (int t = 0; t < EPL; ++t) r[t] += ceq && (uint32_t)c > (uint32_t)e[t];   // ~index: larger = lower index
     }
-    eq0 = eq0 && r0 < rem;
-    eq1 = eq1 && r1 < rem;
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) eq[t] = eq[t] && r[t] < rem;
   }
-  const bool keep0 = gt0 || eq0, keep1 = gt1 || eq1;
-  const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
+  int base = 0;
   const unsigned long long below = (1ull << lane) - 1ull;
-  const int p0 = __popcll(m0 & below), p1 = __popcll(m0) + __popcll(m1 & below);
+#pragma unroll
+  for (int t = 0; t < EPL; ++t) {
+    keep[t] = a[t] > prefix || eq[t];
+    if (WRITE_BACK) {
+      const unsigned long long m = __ballot(keep[t]);
+      if (keep[t]) buf[base + __popcll(m & below)] = e[t];
+      base += __popcll(m);
+    }
+  }
   asm volatile("" ::: "memory");
-  if (keep0) buf[p0] = e0;
-  if (keep1) buf[p1] = e1;
   if (lane == 0) { *cnt = k; *tau = ord2f(prefix); }
   asm volatile("" ::: "memory");
 }
 
+template <int ABL>   // ablation switch for profiling builds (0 = product)
 __global__ __launch_bounds__(256) void memread_select_kernel(const float *__restrict__ keys, long long keys_ostride,
                                                             const float *__restrict__ qk, uint64_t *__restrict__ cand_out,
-                                                            long long n_mem, int n_q, int top_k, long long chunk,
-                                                            int n_split) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float *ktile = reinterpret_cast<float *>(smem);                                  // KT x KLD
-  uint64_t *cand = reinterpret_cast<uint64_t *>(smem + KT * KLD * 4);              // QT x CAP
-  int *cnt = reinterpret_cast<int *>(smem + KT * KLD * 4 + QT * CAP * 8);          // QT
-  float *tau = reinterpret_cast<float *>(smem + KT * KLD * 4 + QT * CAP * 8 + QT * 4);  // QT
+                                                            uint64_t *__restrict__ cand_ws, long long n_mem, int n_q,
+                                                            int top_k, long long chunk, int n_split) {
+  __shared__ __attribute__((aligned(16))) float ktile[KT * KLD];
+  __shared__ int cnt[QT];
+  __shared__ float tau[QT];
+  // this workgroup's candidate buffers in the global workspace: QT x CAP entries
+  uint64_t *cand = cand_ws + (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (QT * CAP);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -153,13 +184,24 @@ __global__ __launch_bounds__(256) void memread_select_kernel(const float *__rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float *arow = ktile + j * KLD + 4 * h;
+    // all 16 fragment reads in flight first (one LDS latency per tile instead of 16 exposed ones: with
+    // 1-2 waves per SIMD nothing else hides them), then 64 back-to-back MFMAs
+    f32x4 afrag[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) afrag[u] = *reinterpret_cast<const f32x4 *>(arow + 8 * u);
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 8 * u);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], qreg[u][s], acc, 0, 0, 0);
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[u][s], qreg[u][s], acc, 0, 0, 0);
     }
 
+    if (ABL == 1 && kb >= c0 + 2 * KT) {   // MFMA + staging only (first two tiles select normally so the lists are valid)
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += acc[r];
+      if (t == 123.456f) my_tau = t;
+      continue;
+    }
     // append in two halves of 8 registers; before each half make room: a half adds <= 16 per query
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -170,7 +212,9 @@ __global__ __launch_bounds__(256) void memread_select_kernel(const float *__rest
         while (need) {
           const int s = wave * 32 + __builtin_ctzll(need);
           need &= need - 1;
-          compact_query(cand + s * CAP, cnt + s, tau + s, top_k, lane);
+          uint64_t e[EPL];
+          bool kp[EPL];
+          compact_query<true>(cand + s * CAP, cnt + s, tau + s, top_k, lane, e, kp);
         }
         my_tau = tau[qslot];
       }
@@ -194,15 +238,24 @@ __global__ __launch_bounds__(256) void memread_select_kernel(const float *__rest
       }
     }
   }
-  // final exact top-k of this chunk for the wave's 32 queries
+  // final exact top-k of this chunk for the wave's 32 queries, written (unsorted) to the chunk list
   for (int qs = 0; qs < 32; ++qs) {
     const int s = wave * 32 + qs;
-    compact_query(cand + s * CAP, cnt + s, tau + s, top_k, lane);
+    uint64_t e[EPL];
+    bool kp[EPL];
+    compact_query<false>(cand + s * CAP, cnt + s, tau + s, top_k, lane, e, kp);
     const int qq = blockIdx.x * QT + s;
-    if (qq < n_q && lane < top_k) {
-      const int n = cnt[s];
-      const uint64_t v = lane < n ? cand[s * CAP + lane] : 0ull;
-      cand_out[(((long long)obj * n_split + split) * n_q + qq) * top_k + lane] = v;
+    if (qq < n_q) {
+      uint64_t *dst = cand_out + (((long long)obj * n_split + split) * n_q + qq) * top_k;
+      const unsigned long long below = (1ull << lane) - 1ull;
+      int kept = 0;
+#pragma unroll
+      for (int t = 0; t < EPL; ++t) {
+        const unsigned long long m = __ballot(kp[t]);
+        if (kp[t]) dst[kept + __popcll(m & below)] = e[t];
+        kept += __popcll(m);
+      }
+      if (lane >= kept && lane < top_k) dst[lane] = 0ull;            // chunk had fewer than k positions
     }
   }
 }
@@ -287,9 +340,15 @@ __global__ __launch_bounds__(64) void memread_finalize_kernel(const uint64_t *__
 struct SplitPlan { int n_split; long long chunk; };
 static SplitPlan plan_split(int n_obj, long long n_mem, int n_q) {
   const long long q_tiles = cdiv(n_q, QT), tiles = cdiv(n_mem, KT);
-  // the 133 KB of LDS per workgroup allow one workgroup per CU: size the split so that the grid is one
-  // round of <= 256 workgroups (more chunks = more per-chunk survivors to select and merge)
-  long long s = 256 / (q_tiles * n_obj);
+  // Selection work grows with the number of chunks (every chunk keeps its own top-k: k(1 + ln(n/k)) appends),
+  // MFMA work does not.  Short memories (480p, T <= ~30): one round of <= 256 workgroups.  Long memories
+  // (>= 512 tiles per chunk, where selection is negligible): up to 3 workgroups per CU so that barriers and
+  // compactions of one workgroup hide behind the MFMAs of the others.
+  const long long wg = q_tiles * n_obj;
+  long long s = 256 / wg;
+  if (s < 1) s = 1;
+  const long long s3 = cdiv(768, wg), by_len = tiles / 512;
+  if (by_len > s) s = by_len < s3 ? by_len : s3;
   if (s > MAX_SPLIT) s = MAX_SPLIT;
   if (s > tiles) s = tiles;
   if (s < 1) s = 1;
@@ -308,15 +367,15 @@ static int run_select(const float *keys, int64_t keys_ostride, const float *qk, 
   if (((uintptr_t)keys & 15) || ((uintptr_t)qk & 15) || (keys_ostride & 3)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read: keys/qk must be 16-byte aligned");
   if (workspace_bytes < mivos_memory_read_workspace_bytes(n_obj, n_mem, n_q, top_k)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read: workspace too small");
   pl = plan_split(n_obj, n_mem, n_q);
-  const size_t lds = KT * KLD * 4 + QT * CAP * 8 + QT * 8;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(memread_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(memread_select): %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(memread_select_kernel, dim3(cdiv(n_q, QT), pl.n_split, n_obj), dim3(256), lds, st, keys,
-                     (long long)keys_ostride, qk, (uint64_t *)workspace, (long long)n_mem, n_q, top_k, pl.chunk, pl.n_split);
+  uint64_t *lists = (uint64_t *)workspace;                                   // [obj][split][q][top_k] chunk survivors
+  uint64_t *bufs = lists + (long long)n_obj * MAX_SPLIT * n_q * top_k;       // [obj][split][q_tile][QT][CAP] candidates
+  static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;   // profiling only
+  if (abl == 1)
+    hipLaunchKernelGGL(memread_select_kernel<1>, dim3(cdiv(n_q, QT), pl.n_split, n_obj), dim3(256), 0, st, keys,
+                       (long long)keys_ostride, qk, lists, bufs, (long long)n_mem, n_q, top_k, pl.chunk, pl.n_split);
+  else
+    hipLaunchKernelGGL(memread_select_kernel<0>, dim3(cdiv(n_q, QT), pl.n_split, n_obj), dim3(256), 0, st, keys,
+                       (long long)keys_ostride, qk, lists, bufs, (long long)n_mem, n_q, top_k, pl.chunk, pl.n_split);
   return check_launch("memread_select");
 }
 
@@ -326,7 +385,7 @@ using namespace mivos;
 
 extern "C" int64_t mivos_memory_read_workspace_bytes(int n_obj, int64_t n_mem, int n_q, int top_k) {
   (void)n_mem;
-  return (int64_t)n_obj * MAX_SPLIT * n_q * top_k * 8;
+  return (int64_t)n_obj * MAX_SPLIT * n_q * top_k * 8 + (int64_t)n_obj * MAX_SPLIT * cdiv(n_q, QT) * QT * CAP * 8;
 }
 
 extern "C" int mivos_memory_read_topk(const float *keys, int64_t keys_ostride, const float *values, int64_t values_ostride,
