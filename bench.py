@@ -68,6 +68,28 @@ class StepTimer:
         self._arm()
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench command, FETCH_SIZE x2 per the gfx950
+    correction of MI355X_MICROARCH.md §HBM).  None if no committed measurement matches."""
+    import glob
+    import re
+    key = re.sub(r"[ ,]", "", kernel_name)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            table = json.load(open(path))
+        except Exception:
+            continue
+        for name, rec in table.items():
+            norm = re.sub(r"[ ,]", "", name.replace("mivos::", ""))
+            norm = re.sub(r"(\d)0>$", r"\1>", norm) if False else norm
+            if norm.startswith(key.rstrip(">")):
+                return dict(bytes_per_launch=int(rec["read_bytes_per_launch"] + rec["write_bytes_per_launch"]),
+                            read=int(rec["read_bytes_per_launch"]), write=int(rec["write_bytes_per_launch"]),
+                            source=os.path.basename(path))
+    return None
+
+
 def conv_roofline(samples):
     """Aggregate the HIP-event samples per kernel instantiation; the dominant one is the roofline kernel."""
     agg = {}
@@ -85,7 +107,7 @@ def conv_roofline(samples):
     ach = flops / secs / 1e12
     peak = F16X3_PEAK_TFLOPS if v >= 10 else MFMA_F32_PEAK_TFLOPS
     roof = dict(bound="mfma", kernel=VARIANT_NAMES[v], achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
-                frac=round(ach / peak, 4), traffic=None, launches_sampled=n,
+                frac=round(ach / peak, 4), traffic=pmc_traffic(VARIANT_NAMES[v]), launches_sampled=n,
                 peak_note=("algorithmic (fp32-equivalent) FLOP/s; kernel issues 3 fp16 MFMA products per term: 2500/3"
                            if v >= 10 else "fp32 MFMA dense peak"),
                 avg_launch_us=round(secs / n * 1e6, 2), algorithmic_gflop_per_launch=round(flops / n / 1e9, 3))

@@ -396,6 +396,219 @@ __global__ __launch_bounds__(512) void conv_f16x3_pipe_kernel(ConvP p, int kpad4
 }
 
 // ------------------------------------------------------------------------------------------------
+// Direct 3x3 / stride 1 / pad 1 convolution for wide layers (decoder, KeyValue, encoder 3x3; Cin % 32 == 0).
+// Ablations of the implicit-GEMM kernel above show it is bound by the vector-memory instruction path: the
+// same input element is loaded, split and written to LDS once per TAP.  Here the block tile is an 8-row x
+// 32-column patch of ONE image: per 32-channel slab the 10 x 34 input patch is loaded + split ONCE into LDS
+// and the 9 taps read their A fragments from it at shifted addresses (80-byte pixel pitch, conflict-free);
+// only the weights stream per tap (double-buffered LDS stages, loads issued per staging pass two steps
+// ahead).  Per K step: 4 B loads + 0.67 A loads per thread instead of 8, 1/6 of the fp32->fp16 splitting.
+// 8 waves = 2 (rows 0-3 / 4-7) x 4 (64 output channels each); wave tile = 4 image rows x 32 px x 64 ch.
+template <int BN>
+__global__ __launch_bounds__(512) void conv3x3_direct_kernel(ConvP p, int kpad4, int tiles_x, int tiles_y) {
+  constexpr int TR = 8, TC = 32, PR = TR + 2, PC = TC + 2;
+  constexpr int PPX = 40;                                  // halves per patch pixel (32 + 8 pad)
+  constexpr int WGN = 4, TN = BN / WGN, NT = TN / 32, MT = 4;
+  constexpr int B_LD = BN / 64;                            // weight staging passes (64 rows per pass)
+  constexpr int NPL = (PR * PC * 8 + 511) / 512;           // float4 patch loads per thread and slab
+  constexpr int PATCH = 2 * PR * PC * PPX;                 // halves: hi image | lo image
+  constexpr int BSTAGE = 2 * BN * PITCH2;                  // halves: Bh | Bl
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *Ph = reinterpret_cast<_Float16 *>(smem_raw);
+  _Float16 *Pl = Ph + PR * PC * PPX;
+  _Float16 *Bs = Ph + PATCH;                               // two weight stages
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = t % p.tiles_n; t /= p.tiles_n;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int img = t / tiles_y;
+  const int y0 = ty * TR, x0 = tx * TC, n0 = nt * BN;
+  const float *xb = p.x + (long long)img * p.x_ns;
+  const float relu_floor = p.relu_in ? 0.f : -INFINITY;
+
+  const int k4 = tid & 7, lrow = tid >> 3;
+  const f32x4 *b_ptr[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int n = n0 + lrow + 64 * j;
+    b_ptr[j] = reinterpret_cast<const f32x4 *>(p.w) + (long long)(n < p.Cout ? n : p.Cout - 1) * kpad4 + k4;
+  }
+  // patch element e -> (pixel, float4 channel group); offsets inside the image are slab independent
+  long long p_off[NPL];
+  bool p_ok[NPL];
+#pragma unroll
+  for (int l = 0; l < NPL; ++l) {
+    const int e = tid + 512 * l;
+    const int px = e >> 3, c4 = e & 7;
+    const int pr = px / PC, pc = px - pr * PC;
+    const int iy = y0 + pr - 1, ix = x0 + pc - 1;
+    p_ok[l] = e < PR * PC * 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    p_off[l] = p_ok[l] ? ((long long)iy * p.W + ix) * p.x_ps + 4 * c4 : 0ll;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  f32x4 pa[NPL], rb[B_LD];
+  const int n_slab = p.Cin >> 5, n_step = n_slab * 9;
+
+  auto load_patch = [&](int slab) {
+#pragma unroll
+    for (int l = 0; l < NPL; ++l) {
+      f32x4 v = *reinterpret_cast<const f32x4 *>(xb + p_off[l] + (p_ok[l] ? 32 * slab : 0));
+      v.x = p_ok[l] ? v.x : 0.f; v.y = p_ok[l] ? v.y : 0.f; v.z = p_ok[l] ? v.z : 0.f; v.w = p_ok[l] ? v.w : 0.f;
+      pa[l] = v;
+    }
+  };
+  auto write_patch = [&]() {
+#pragma unroll
+    for (int l = 0; l < NPL; ++l) {
+      const int e = tid + 512 * l;
+      if (e < PR * PC * 8) {
+        f32x4 v = pa[l];
+        v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+        h4 hi, lo;
+        hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
+        lo.x = (_Float16)(v.x - (float)hi.x); lo.y = (_Float16)(v.y - (float)hi.y);
+        lo.z = (_Float16)(v.z - (float)hi.z); lo.w = (_Float16)(v.w - (float)hi.w);
+        const int off = (e >> 3) * PPX + 4 * (e & 7);
+        *reinterpret_cast<h4 *>(Ph + off) = hi;
+        *reinterpret_cast<h4 *>(Pl + off) = lo;
+      }
+    }
+  };
+  auto load_b = [&](int step, int j) {                     // weights of K step `step` (= slab * 9 + tap), pass j
+    const int st = step < n_step ? step : n_step - 1;
+    rb[j] = b_ptr[j][st * 8];
+  };
+  auto write_b = [&](_Float16 *stg, int j) {
+    const int off = (lrow + 64 * j) * PITCH2 + 4 * k4;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 hh, ll;
+    hh.x = rb[j].x; hh.y = rb[j].y; ll.x = rb[j].z; ll.y = rb[j].w;
+    *reinterpret_cast<f32x2 *>(stg + off) = hh;
+    *reinterpret_cast<f32x2 *>(stg + BN * PITCH2 + off) = ll;
+  };
+
+  // prologue: patch of slab 0, weights of step 0 in stage 0, weights of step 1 in registers
+  load_patch(0);
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) load_b(0, j);
+  write_patch();
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) write_b(Bs, j);
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) load_b(1, j);
+  if (n_slab > 1) load_patch(1);
+  __syncthreads();
+
+  const int i = lane & 31, h = lane >> 5;
+  int step = 0;
+  for (int slab = 0; slab < n_slab; ++slab) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap, ++step) {
+      const int kh = tap / 3, kw = tap - 3 * kh;
+      const _Float16 *cur = Bs + (step & 1) * BSTAGE;
+      _Float16 *nxt = Bs + ((step + 1) & 1) * BSTAGE;
+      const _Float16 *pB = cur + (wn * TN + i) * PITCH2 + 8 * h;
+      const int aoff = ((wm * 4 + kh) * PC + i + kw) * PPX + 8 * h;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        h8 bh[NT], bl[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          bh[j] = *reinterpret_cast<const h8 *>(pB + j * 32 * PITCH2 + kk * 16);
+          bl[j] = *reinterpret_cast<const h8 *>(pB + BN * PITCH2 + j * 32 * PITCH2 + kk * 16);
+        }
+#pragma unroll
+        for (int r = 0; r < MT; ++r) {
+          const h8 ah = *reinterpret_cast<const h8 *>(Ph + aoff + r * PC * PPX + kk * 16);
+          const h8 al = *reinterpret_cast<const h8 *>(Pl + aoff + r * PC * PPX + kk * 16);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[r][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[r][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[r][j], 0, 0, 0);
+          // weight staging of the next step + loads of the one after, one pass behind each MFMA group
+          const int sg = kk * MT + r;
+          if (sg < B_LD) { write_b(nxt, sg); load_b(step + 2, sg); }
+        }
+      }
+      if (tap == 8 && slab + 1 < n_slab) {
+        __syncthreads();                                   // everybody is done reading this slab's patch
+        write_patch();
+        if (slab + 2 < n_slab) load_patch(slab + 2);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: vectorised through per-wave LDS scratch (stages are dead)
+  float *scratch = reinterpret_cast<float *>(smem_raw) + wave * 32 * EPI_PITCH;
+  const int prow0 = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * TN + j * 32 + c4;
+    const bool nok = n < p.Cout;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+    if (nok && p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + n);
+    if (nok && p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + n);
+    float *dst;
+    long long d_ns, d_ps;
+    int dn;
+    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_ps = p.y_ps; dn = n; }
+    else { dst = p.y2; d_ns = p.y2_ns; d_ps = p.y2_ps; dn = n - p.split; }
+#pragma unroll
+    for (int r = 0; r < MT; ++r) {
+      const int y = y0 + wm * 4 + r;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) scratch[mfma32_row(q, lane) * EPI_PITCH + (lane & 31)] = acc[r][j][q];
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int col = ps * 8 + prow0, x = x0 + col;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(scratch + col * EPI_PITCH + c4);
+        if (y < p.H && x < p.W && nok) {
+          const long long pix = (long long)y * p.W + x;
+          v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
+          if (p.res) {
+            const f32x4 rr = *reinterpret_cast<const f32x4 *>(p.res + (long long)img * p.r_ns + pix * p.r_ps + n);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+          if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          *reinterpret_cast<f32x4 *>(dst + (long long)img * d_ns + pix * d_ps + dn) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BN>
+static int launch_direct3x3(ConvP &p, hipStream_t st) {
+  const int tiles_x = cdiv(p.W, 32), tiles_y = cdiv(p.H, 8);
+  p.tiles_n = cdiv(p.Cout, BN);
+  const size_t lds = (2ull * 10 * 34 * 40 + 2ull * 2 * BN * PITCH2) * sizeof(_Float16);
+  auto kern = conv3x3_direct_kernel<BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(conv3x3_direct): %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int kpad4 = cdiv(p.Ktot, BKH) * BKH / 4;
+  hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y * p.N * p.tiles_n), dim3(512), lds, st, p, kpad4, tiles_x, tiles_y);
+  return check_launch("conv3x3_direct");
+}
+
+// ------------------------------------------------------------------------------------------------
 // Direct 3x3 / stride 1 / pad 1 convolution with 32 output channels (FusionNet body, fusion_net.py:12-27).
 // As an implicit GEMM these layers (N = 32, K = 144/288, 2 M pixels at 480p x 5 objects) are staging-bound:
 // every input element is converted and written to LDS nine times for 32*3 MFMA MACs each.  Here a
@@ -630,6 +843,15 @@ int select_variant_f16x3(int M, int Cout) {
 int launch_conv_f16x3(ConvP &p, hipStream_t st) {
   if (p.vec_epi && p.Cout == 32 && p.split == 32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && (p.Cin == 16 || p.Cin == 32))
     return p.Cin == 16 ? launch_n32_direct<16>(p, st) : launch_n32_direct<32>(p, st);
+  // direct 3x3 (LDS patch reuse) for wide stride-1 layers with enough 8x32 tiles to fill the chip
+  // Measured equal to the pipelined implicit GEMM on the decoder shapes (302 vs 307 TFLOP/s) although it
+  // issues 45 % fewer vector-memory instructions and 40 % fewer LDS writes, i.e. neither of those bounds
+  // the GEMM today; kept selectable (MIVOS_DIRECT3X3_MIN_TILES=<n>, 0 forces it) for the next tuning round.
+  const char *mt = getenv("MIVOS_DIRECT3X3_MIN_TILES");
+  const long long min_tiles = mt ? atoll(mt) : (1ll << 60);
+  if (p.vec_epi && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && (p.Cin & 31) == 0 && p.Cout >= 224 &&
+      (long long)p.N * cdiv(p.H, 8) * cdiv(p.W, 32) * cdiv(p.Cout, 256) >= min_tiles)
+    return launch_direct3x3<256>(p, st);
   switch (select_variant_f16x3(p.M, p.Cout)) {
     case 5: {
       static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;   // profiling only

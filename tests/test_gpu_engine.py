@@ -157,3 +157,86 @@ def test_480p_propagation_vs_oracle(nets, synthetic_states, K):
         print(f"K={K} interact({idx}): IoU {iou:.6f} max|dprob| {dp:.2e}")
         assert iou >= 0.999
         assert dp < 2.5e-3
+
+
+# ------------------------------------------------------------------ InferenceCore behaviour / edge cases
+
+def _small_session(prop, fuse, images, gt, K, order, **kw):
+    core = InferenceCore(prop, fuse, images, K, device=DEV, **kw)
+    out = None
+    for idx in order:
+        out = core.interact(gt[idx], idx)
+    return core, out
+
+
+def test_mem_profiles_give_identical_results(nets):
+    """mem_profile only moves buffers between host and HBM and bounds the caches (reference :44-63): results
+    must be bit-identical, including after a cache flush (q_buf_size = 1 for profile 3)."""
+    prop, fuse = nets
+    images, gt = O.synthetic_clip(6, 100, 141, 2, seed=41)          # H, W not multiples of 16
+    ref_core, ref = _small_session(prop, fuse, images, gt, 2, [0, 5], mem_freq=2, mem_profile=0)
+    for mp in (1, 2, 3):
+        core, out = _small_session(prop, fuse, images, gt, 2, [0, 5], mem_freq=2, mem_profile=mp)
+        assert np.array_equal(out, ref), mp
+        assert torch.equal(core.prob.cpu(), ref_core.prob.cpu()), mp
+        assert core.images.device.type == "cpu" and core.prob.device.type == ("cuda" if mp == 1 else "cpu")
+    assert ref.shape == (6, 100, 141) and ref_core.pad == (1, 2, 6, 6) and ref_core.prob.shape == (3, 6, 1, 112, 144)
+
+
+def test_interaction_order_and_reinteraction_vs_oracle(nets, synthetic_states):
+    """Last frame first, then the first frame (pure backward + fused pass), then the SAME frame again
+    (certain memory grows by a duplicate, exactly like the reference's torch.cat at :243-245)."""
+    prop, fuse = nets
+    sd, fsd = synthetic_states
+    images, gt = O.synthetic_clip(5, 128, 160, 1, seed=43)
+    core = InferenceCore(prop, fuse, images, 1, mem_freq=1, device=DEV)
+    ocore = O.OracleCore(sd, fsd, images, 1, mem_freq=1, top_k=20)
+    for idx in (4, 0, 0):
+        out, ref = core.interact(gt[idx], idx), ocore.interact(gt[idx], idx)
+        assert mean_iou(out, ref, 1) >= 0.999
+        assert float((core.prob.cpu() - ocore.prob).abs().max()) < 2.5e-3
+    assert core.certain_mem_k.shape == (1, 128, 3, 8, 10) and core.certain_mem_v.shape == (1, 512, 3, 8, 10)
+    assert core.propagated_frames == ocore.propagated
+
+
+def test_callbacks_and_single_frame_clip(nets):
+    prop, fuse = nets
+    images, gt = O.synthetic_clip(4, 128, 160, 2, seed=44)
+    core = InferenceCore(prop, fuse, images, 2, mem_freq=5, device=DEV)
+    totals, steps = [], []
+    core.interact(gt[1], 1, total_cb=totals.append, step_cb=lambda: steps.append(1))
+    assert totals == [3] and len(steps) == 3                       # front 4 - back -1 - 2 = 3 frames to process
+    one, gt1 = O.synthetic_clip(1, 128, 160, 2, seed=45)
+    c1 = InferenceCore(prop, fuse, one, 2, device=DEV)
+    m = c1.interact(gt1[0], 0)                                      # nothing to propagate: mask is the input
+    assert np.array_equal(m[0], gt1[0].argmax(0)[0].numpy().astype(np.uint8))
+
+
+def test_topk_larger_than_memory_raises_like_reference(nets):
+    """64x96 frame -> 24 memory positions at T=1 < top_k=50: the reference dies in torch.topk
+    ('selected index k out of range'); so do we (SURVEY.md §7 hard part 2)."""
+    prop50 = PropagationNetwork(top_k=50)
+    prop50.load_state_dict(nets[0].state_dict())
+    images, gt = O.synthetic_clip(3, 64, 96, 1, seed=46)
+    core = InferenceCore(prop50, nets[1], images, 1, device=DEV)
+    with pytest.raises(RuntimeError, match="out of range"):
+        core.interact(gt[0], 0)
+
+
+def test_1080p_memory_read_and_single_step_vs_oracle(nets, synthetic_states):
+    """BASELINE config 5 geometry (1080x1920 -> 1088x1920, HW = 8160), K = 1, T = 1: keys / values / logits."""
+    prop, _ = nets
+    sd = synthetic_states[0]
+    images, gt = O.synthetic_clip(2, 1080, 1920, 1, seed=47)
+    img, _ = O.pad_divide_by(images, 16)
+    m0, _ = O.pad_divide_by(gt[0], 16)
+    ok, ov = O.memorize(sd, img[:, 0], m0[1:])
+    oq = O.get_query_values(sd, img[:, 1])
+    ref = O.segment_logits(sd, ok, ov, *oq, top_k=20)[:, 0]
+    k, v = prop.memorize_into(img[:, 0].to(DEV), m0[1:].to(DEV))
+    assert k.shape == (1, 68, 120, 128)
+    q = prop.encode_query(img[:, 1].to(DEV))
+    got = prop.segment(k.reshape(1, -1, 128), v.reshape(1, -1, 512), q, logits=True).cpu()
+    d = (got - ref).abs()
+    print(f"1080p: max|dlogit| {float(d.max()):.2e}  frac(|d|>1e-3) {float((d > 1e-3).float().mean()):.2e}")
+    assert float(d.max()) < 2e-3 and float((d > LOGIT_TOL).float().mean()) < 1e-4

@@ -100,6 +100,30 @@ def test_conv2d_strided_views_split_and_broadcast_residual(precision):
     assert float(bank_a[:, [0, 1, 3]].abs().max()) == 0 and float(bank_b[..., :10].abs().max()) == 0 and float(bank_b[..., 74:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 256, 21, 45), (1, 128, 640, 9, 33), (3, 32, 512, 8, 32)])
+def test_conv3x3_direct_patch_kernel_ragged(shape, monkeypatch):
+    """The LDS-patch-reuse 3x3 kernel (normally only picked for >= 200 tiles) on ragged images: partial 8x32
+    tiles, several 32-channel slabs, Cout not a multiple of 256, pre-activation + residual + split."""
+    monkeypatch.setenv("MIVOS_DIRECT3X3_MIN_TILES", "0")
+    n, cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(n, cout, h, w, generator=g)
+    ref = F.relu(F.conv2d(F.relu(x).double(), wt.double(), b.double(), padding=1) + res.double())
+    L = ConvLayer.pack(wt, b, None, 1, 1)
+    L.split = 128
+    L = L.to(DEV)
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f16x3"
+    try:
+        y1, y2 = ops.conv(nhwc(x).to(DEV), L, relu_in=True, relu_out=True, res=nhwc(res).to(DEV))
+    finally:
+        ops.CONV_PRECISION = old
+    got = torch.cat([y1, y2], -1).cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < 2e-6
+
+
 def test_conv_rejects_bad_arguments():
     L = ConvLayer.pack(torch.randn(8, 12, 3, 3), None, None, 1, 1).to(DEV)
     with pytest.raises(ops.MivosHipError):
