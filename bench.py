@@ -82,7 +82,6 @@ def pmc_traffic(kernel_name):
             continue
         for name, rec in table.items():
             norm = re.sub(r"[ ,]", "", name.replace("mivos::", ""))
-            norm = re.sub(r"(\d)0>$", r"\1>", norm) if False else norm
             if norm.startswith(key.rstrip(">")):
                 return dict(bytes_per_launch=int(rec["read_bytes_per_launch"] + rec["write_bytes_per_launch"]),
                             read=int(rec["read_bytes_per_launch"]), write=int(rec["write_bytes_per_launch"]),
