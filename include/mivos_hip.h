@@ -77,6 +77,10 @@ typedef struct {
   int64_t y_nstride, y_pstride;
   int64_t y2_nstride, y2_pstride;
   int64_t res_nstride, res_pstride; /* res_nstride == 0 broadcasts one residual over the batch   */
+  void *workspace;         /* optional device scratch for split-K (small-M layers: K is cut into slices whose
+                              fp32 partial tiles are summed in a fixed order by a second kernel: deterministic);
+                              NULL or too small = no split-K                                              */
+  int64_t workspace_bytes;
 } mivos_conv_desc;
 
 int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream);

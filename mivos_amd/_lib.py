@@ -20,7 +20,8 @@ class ConvDesc(C.Structure):
                 ("stride", i32), ("pad", i32), ("Ho", i32), ("Wo", i32), ("split", i32),
                 ("relu_in", i32), ("relu_out", i32), ("precision", i32),
                 ("x_nstride", i64), ("x_pstride", i64), ("y_nstride", i64), ("y_pstride", i64),
-                ("y2_nstride", i64), ("y2_pstride", i64), ("res_nstride", i64), ("res_pstride", i64)]
+                ("y2_nstride", i64), ("y2_pstride", i64), ("res_nstride", i64), ("res_pstride", i64),
+                ("workspace", vp), ("workspace_bytes", i64)]
 
 
 class InterleaveDesc(C.Structure):

@@ -9,6 +9,9 @@ struct ConvP {
   float *y, *y2;
   int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, split, relu_in, relu_out;
   int log2Cin, M, Ktot, HoWo, tiles_n, vec_epi;
+  int kt_split;        // split-K: K steps per slice (gridDim.y slices), 0 = off
+  float *partial;      // split-K: [slice][M][Cout] fp32 partial sums
+  void *ws; long long ws_bytes;
   long long x_ns, x_ps, y_ns, y_ps, y2_ns, y2_ps, r_ns, r_ps;
 };
 

@@ -150,10 +150,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvP p, int kpad4) 
     }
   };
 
-  const int nk = (p.Ktot + BKH - 1) / BKH;
-  gload(0);
+  // split-K (small-M layers): gridDim.y slices of kt_split K steps each; partial tiles go to p.partial
+  const int nk_all = (p.Ktot + BKH - 1) / BKH;
+  const int kt0 = p.kt_split ? blockIdx.y * p.kt_split : 0;
+  const int nk = p.kt_split ? (kt0 + p.kt_split < nk_all ? kt0 + p.kt_split : nk_all) : nk_all;
+  gload(kt0 * BKH);
   const int frag = (lane & 31) * PITCH + 8 * (lane >> 5);
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     __syncthreads();                       // everybody is done reading the previous stage
     lwrite();
     __syncthreads();
@@ -190,6 +193,18 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvP p, int kpad4) 
     }
   }
 
+  if (p.kt_split) {     // raw fp32 partial tile of this K slice: [slice][M][Cout], dense
+    ConvP q = p;
+    q.scale = q.bias = q.res = nullptr;
+    q.relu_out = 0;
+    q.split = p.Cout;
+    q.y = p.partial + (long long)blockIdx.y * p.M * p.Cout;
+    q.y_ps = p.Cout;
+    q.y_ns = (long long)p.HoWo * p.Cout;
+    __syncthreads();
+    epilogue_vec<MT, NT>(acc, reinterpret_cast<float *>(smem_raw) + wave * 32 * EPI_PITCH, q, m0 + wm * TM, n0 + wn * TN, lane);
+    return;
+  }
   if (p.vec_epi) {
     __syncthreads();   // LDS stages are dead: reuse them as per-wave transpose scratch
     epilogue_vec<MT, NT>(acc, reinterpret_cast<float *>(smem_raw) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
@@ -792,10 +807,50 @@ __global__ void pack_weights_f16x3_kernel(const float *__restrict__ w, _Float16 
   }
 }
 
+// split-K second pass: y = act(sum_s partial[s] * scale + bias + res), slices summed in ascending order
+__global__ void splitk_reduce_kernel(ConvP p, int n_slices) {
+  const int c4n = p.Cout >> 2;
+  const long long total = (long long)p.M * c4n;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(e / c4n), n = (int)(e - (long long)m * c4n) * 4;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(p.partial + (long long)m * p.Cout + n);
+    f32x4 v = src[0];
+    for (int s = 1; s < n_slices; ++s) {
+      const f32x4 t = src[(long long)s * p.M * c4n];
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const int img = m / p.HoWo, pix = m - img * p.HoWo;
+    if (p.scale) { const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + n); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+    if (p.bias) { const f32x4 bi = *reinterpret_cast<const f32x4 *>(p.bias + n); v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
+    if (p.res) {
+      const f32x4 rr = *reinterpret_cast<const f32x4 *>(p.res + (long long)img * p.r_ns + (long long)pix * p.r_ps + n);
+      v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+    }
+    if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    float *dst;
+    long long d_ns, d_ps;
+    int dn;
+    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_ps = p.y_ps; dn = n; }
+    else { dst = p.y2; d_ns = p.y2_ns; d_ps = p.y2_ps; dn = n - p.split; }
+    *reinterpret_cast<f32x4 *>(dst + (long long)img * d_ns + (long long)pix * d_ps + dn) = v;
+  }
+}
+
 template <int BM, int BN, int WGM, int WGN>
 static int launch_f16x3(ConvP &p, hipStream_t st) {
   const int tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.Cout, BN);
+  // split-K when the tile grid cannot fill the chip and K is long (batch-1 / 30x54 layers)
+  const int nk = cdiv(p.Ktot, BKH), wgs = tiles_m * p.tiles_n;
+  int slices = 1;
+  if (p.vec_epi && p.ws && wgs < 400 && nk >= 8) {
+    slices = (640 + wgs / 2) / wgs;                       // aim at ~2.5 workgroups per CU
+    if (slices > 8) slices = 8;
+    if (slices > nk / 4) slices = nk / 4;
+    if ((long long)slices * p.M * p.Cout * 4 > p.ws_bytes) slices = 1;
+  }
+  p.kt_split = 0;
+  if (slices > 1) { p.kt_split = cdiv(nk, slices); slices = cdiv(nk, p.kt_split); p.partial = (float *)p.ws; }
   const size_t lds = 2ull * (BM + BN) * PITCH * sizeof(_Float16);
   auto kern = conv_f16x3_kernel<BM, BN, WGM, WGN>;
   static bool attr_set = false;
@@ -805,7 +860,12 @@ static int launch_f16x3(ConvP &p, hipStream_t st) {
     attr_set = true;
   }
   const int kpad4 = cdiv(p.Ktot, BKH) * BKH / 4;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(256), lds, st, p, kpad4);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n, slices), dim3(256), lds, st, p, kpad4);
+  if (slices > 1) {
+    const long long total = (long long)p.M * (p.Cout / 4);
+    const int blocks = (int)(total / 256 + 1 < 2048 ? total / 256 + 1 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, slices);
+  }
   return check_launch("conv_f16x3");
 }
 

@@ -228,6 +228,7 @@ int conv_params_from_desc(const mivos_conv_desc *d, ConvP &p) {
   p.HoWo = d->Ho * d->Wo; p.M = d->N * p.HoWo; p.Ktot = d->KH * d->KW * d->Cin; p.tiles_n = 1;
   p.x_ns = d->x_nstride; p.x_ps = d->x_pstride; p.y_ns = d->y_nstride; p.y_ps = d->y_pstride;
   p.y2_ns = d->y2_nstride; p.y2_ps = d->y2_pstride; p.r_ns = d->res_nstride; p.r_ps = d->res_pstride;
+  p.kt_split = 0; p.partial = nullptr; p.ws = d->workspace; p.ws_bytes = d->workspace_bytes;
   auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
   p.vec_epi = !(p.Cout & 3) && !(p.split & 3) && !((p.y_ns | p.y_ps) & 3) && al16(p.y) && al16(p.scale) && al16(p.bias) &&
               (!dual || (!((p.y2_ns | p.y2_ps) & 3) && al16(p.y2))) && (!p.res || (!((p.r_ns | p.r_ps) & 3) && al16(p.res)));

@@ -16,6 +16,7 @@ _checked_devices = set()
 # "f16x3": error-compensated fp16 MFMA convolutions (3 products per term, fp32-class accuracy, 5.3x the
 # fp32-MFMA rate); "f32": exact fp32 MFMA everywhere (the verification path).
 CONV_PRECISION = "f16x3"
+SPLITK_WORKSPACE_BYTES = 64 << 20      # scratch handed to mivos_conv2d_fused for split-K partial tiles
 # bench.py sets this to a list to time every conv launch with HIP events on the launch stream:
 # entries (kernel variant [+10 for the f16x3 back-end], algorithmic FLOPs = 2*M*Cout*KH*KW*Cin, start event, end event)
 PROFILE = None
@@ -153,6 +154,8 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None):
         d.res = _f32(res).data_ptr()
         rn, rp = _nhwc_strides(res)
         d.res_nstride, d.res_pstride = (0 if (res.shape[0] == 1 and n > 1) else rn), rp
+    ws = _workspace(SPLITK_WORKSPACE_BYTES, x.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -161,6 +164,8 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None):
         ev1.record()
         m = n * ho * wo
         var = _lib.load().mivos_conv2d_variant_f16x3(m, L.cout) + 10 if d.precision == 1 else _lib.load().mivos_conv2d_variant(m, L.cout)
+        if d.precision == 1 and L.cout == 32 and L.k == 3 and L.stride == 1 and cin in (16, 32):
+            var = 19
         PROFILE.append((var, 2.0 * m * L.cout * L.k * L.k * cin, ev0, ev1, (m, cin, L.cout, L.k, L.stride)))
     return (out, out2) if dual else out
 
