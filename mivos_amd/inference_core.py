@@ -116,12 +116,26 @@ class InferenceCore:
             self.image_buf[idx] = self.images[:, idx].to(self.device)
         return self.image_buf[idx]
 
-    def _query(self, idx):
+    QUERY_BATCH = 4      # frames encoded together on a cache miss (when the cache has room for them)
+
+    def _query(self, idx, upcoming=()):
+        """Cached query features of frame idx.  On a miss the next not-yet-cached frames of the running pass
+        (`upcoming`, in processing order) are encoded in the same batch: the features are state independent,
+        so this is the reference's lazy cache (:110-120) filled a few frames ahead."""
         q = self.query_buf.get(idx)
         if q is None:
             if len(self.query_buf) > self.q_buf_size:
                 self.query_buf = {}
-            q = self.query_buf[idx] = self.prop_net.encode_query(self.get_image_buffered(idx))
+            room = self.q_buf_size + 1 - len(self.query_buf)
+            todo = [idx] + [t for t in upcoming if t != idx and t not in self.query_buf]
+            todo = todo[:max(1, min(self.QUERY_BATCH, room))]
+            if len(todo) == 1:
+                q = self.query_buf[idx] = self.prop_net.encode_query(self.get_image_buffered(idx))
+            else:
+                frames = torch.cat([self.get_image_buffered(t) for t in todo], 0)
+                for t, qt in zip(todo, self.prop_net.encode_query_batch(frames)):
+                    self.query_buf[t] = qt
+                q = self.query_buf[idx]
         return q
 
     def get_query_kv_buffered(self, idx):
@@ -139,8 +153,8 @@ class InferenceCore:
         values = torch.empty((K, total, kh, kw, CV), dtype=torch.float32, device=self.device)
         keys[:, :nc], values[:, :nc] = self._certain_k, self._certain_v
         hw = kh * kw
-        for st in steps:
-            q = self._query(st.ti)
+        for si, st in enumerate(steps):
+            q = self._query(st.ti, upcoming=[s2.ti for s2 in steps[si + 1:si + 8]])
             prob_k = self.prop_net.segment(keys[:, :st.n_read].reshape(K, st.n_read * hw, CK),
                                            values[:, :st.n_read].reshape(K, st.n_read * hw, CV), q)
             out = ops.aggregate(prob_k.unsqueeze(1), keep_bg=True)            # [K+1,1,nh,nw]
