@@ -116,7 +116,7 @@ class InferenceCore:
             self.image_buf[idx] = self.images[:, idx].to(self.device)
         return self.image_buf[idx]
 
-    QUERY_BATCH = 4      # frames encoded together on a cache miss (when the cache has room for them)
+    QUERY_BATCH = 8      # frames encoded together on a cache miss (when the cache has room for them)
 
     def _query(self, idx, upcoming=()):
         """Cached query features of frame idx.  On a miss the next not-yet-cached frames of the running pass
@@ -154,7 +154,7 @@ class InferenceCore:
         keys[:, :nc], values[:, :nc] = self._certain_k, self._certain_v
         hw = kh * kw
         for si, st in enumerate(steps):
-            q = self._query(st.ti, upcoming=[s2.ti for s2 in steps[si + 1:si + 8]])
+            q = self._query(st.ti, upcoming=[s2.ti for s2 in steps[si + 1:si + 16]])
             prob_k = self.prop_net.segment(keys[:, :st.n_read].reshape(K, st.n_read * hw, CK),
                                            values[:, :st.n_read].reshape(K, st.n_read * hw, CV), q)
             out = ops.aggregate(prob_k.unsqueeze(1), keep_bg=True)            # [K+1,1,nh,nw]
