@@ -326,7 +326,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_pipe_kernel(ConvP p, int kpad4
   };
   // convert + write one staging pass (A pass s and B pass s) of the prefetched registers into stage `st`
   auto lwrite_seg = [&](_Float16 *st, int s) {
-    if (ABL == 2) return;   // no conversion / LDS writes
+    if (ABL == 2 || ABL == 6) return;   // no conversion / LDS writes
     if (s < A_LD) {
       f32x4 v = ra[s];
       v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
@@ -359,13 +359,14 @@ __global__ __launch_bounds__(512) void conv_f16x3_pipe_kernel(ConvP p, int kpad4
       h8 bh[NT], bl[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
+        if (ABL == 6) { bh[j] = h8{1, 2, 3, 4, 5, 6, 7, 8}; bl[j] = h8{8, 7, 6, 5, 4, 3, 2, 1}; continue; }   // no LDS reads
         bh[j] = *reinterpret_cast<const h8 *>(pB + j * 32 * PITCH2 + kk * 16);
         bl[j] = *reinterpret_cast<const h8 *>(pB + BN * PITCH2 + j * 32 * PITCH2 + kk * 16);
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const h8 ah = *reinterpret_cast<const h8 *>(pA + i * 32 * PITCH2 + kk * 16);
-        const h8 al = *reinterpret_cast<const h8 *>(pA + BM * PITCH2 + i * 32 * PITCH2 + kk * 16);
+        const h8 ah = ABL == 6 ? h8{1, 1, 2, 2, 3, 3, 4, 4} : *reinterpret_cast<const h8 *>(pA + i * 32 * PITCH2 + kk * 16);
+        const h8 al = ABL == 6 ? h8{4, 4, 3, 3, 2, 2, 1, 1} : *reinterpret_cast<const h8 *>(pA + BM * PITCH2 + i * 32 * PITCH2 + kk * 16);
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
@@ -919,6 +920,7 @@ int launch_conv_f16x3(ConvP &p, hipStream_t st) {
       if (abl == 2) return launch_f16x3_pipe<256, 256, 2, 4, 2>(p, st);
       if (abl == 3) return launch_f16x3_pipe<256, 256, 2, 4, 3>(p, st);
       if (abl == 4) return launch_f16x3_pipe<256, 256, 2, 4, 4>(p, st);
+      if (abl == 6) return launch_f16x3_pipe<256, 256, 2, 4, 6>(p, st);
       return launch_f16x3_pipe<256, 256, 2, 4>(p, st);
     }
     case 6: return launch_f16x3_pipe<128, 256, 2, 4>(p, st);
