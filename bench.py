@@ -37,7 +37,9 @@ VARIANT_NAMES = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<64,6
                  10: "conv_f16x3_kernel<128,128,2,2>", 11: "conv_f16x3_kernel<64,64,2,2>", 12: "conv_f16x3_kernel<128,32,4,1>",
                  13: "conv_f16x3_kernel<128,64,2,2>", 14: "conv_cout1_kernel", 15: "conv_f16x3_pipe_kernel<256,256,2,4>",
                  16: "conv_f16x3_pipe_kernel<128,256,2,4>", 17: "conv_f16x3_pipe_kernel<128,128,4,2>",
-                 18: "conv_f16x3_pipe_kernel<64,256,2,4>", 19: "conv3x3_n32_direct_kernel"}
+                 18: "conv_f16x3_pipe_kernel<64,256,2,4>", 19: "conv3x3_n32_direct_kernel",
+                 20: "conv_f16x3_pp_kernel<128,128,2,4,0>", 21: "conv_f16x3_pp_kernel<128,256,2,4,0>",
+                 22: "conv_f16x3_pp_kernel<128,64,4,2,0>", 23: "conv_f16x3_pp_kernel<256,256,2,4,0>"}
 
 
 class StepTimer:
@@ -92,24 +94,28 @@ def pmc_traffic(kernel_name):
 def conv_roofline(samples):
     """Aggregate the HIP-event samples per kernel instantiation; the dominant one is the roofline kernel."""
     agg = {}
-    for variant, flops, e0, e1, _shape in samples:
-        a = agg.setdefault(variant, [0.0, 0.0, 0])
+    for variant, flops, e0, e1, shape in samples:
+        a = agg.setdefault(variant, [0.0, 0.0, 0, 0.0])
         a[0] += flops
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
+        m, cin, cout, k, stride, has_res = shape
+        # one read of the fp32 input, the (hi, lo) fp16 weights and the residual, one write of the fp32 output
+        a[3] += 4.0 * m * stride * stride * cin + 4.0 * cout * k * k * cin + 4.0 * m * cout * (2 if has_res else 1)
     if not agg:
         return None, {}
     table = {VARIANT_NAMES[v]: dict(launches=a[2], avg_us=round(a[1] / a[2] * 1e6, 2), tflops=round(a[0] / a[1] / 1e12, 2),
                                     time_share=round(a[1] / sum(x[1] for x in agg.values()), 3)) for v, a in sorted(agg.items())}
     dom = max(agg.items(), key=lambda kv: kv[1][1])
-    v, (flops, secs, n) = dom
+    v, (flops, secs, n, abytes) = dom
     ach = flops / secs / 1e12
     peak = F16X3_PEAK_TFLOPS if v >= 10 else MFMA_F32_PEAK_TFLOPS
     roof = dict(bound="mfma", kernel=VARIANT_NAMES[v], achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
                 frac=round(ach / peak, 4), traffic=pmc_traffic(VARIANT_NAMES[v]), launches_sampled=n,
                 peak_note=("algorithmic (fp32-equivalent) FLOP/s; kernel issues 3 fp16 MFMA products per term: 2500/3"
                            if v >= 10 else "fp32 MFMA dense peak"),
-                avg_launch_us=round(secs / n * 1e6, 2), algorithmic_gflop_per_launch=round(flops / n / 1e9, 3))
+                avg_launch_us=round(secs / n * 1e6, 2), algorithmic_gflop_per_launch=round(flops / n / 1e9, 3),
+                algorithmic_bytes_per_launch=int(abytes / n))
     return roof, table
 
 

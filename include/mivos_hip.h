@@ -72,7 +72,10 @@ typedef struct {
                             w points to weights packed by mivos_pack_weights_f16x3 (hi/lo fp16, scaled by a
                             power of two 2^s; the caller folds 2^-s into `scale`); acc is fp32 and
                             sums hi*hi + hi*lo + lo*hi, i.e. ~2^-22 relative product error (fp32 class).
-                            Cout == 1 layers always take the fp32 dot-product kernel (w = fp32 OHWI).   */
+                            Cout == 1 layers always take the fp32 dot-product kernel (w = fp32 OHWI).
+                         2: as 1, but x is already split (SH32 layout, see mivos_pack_activation_sh32), w is
+                            packed by mivos_pack_weights_f16x3_dma and both operands are staged by LDS-DMA;
+                            Cin % 32 == 0, relu_in must be 0.                                            */
   int64_t x_nstride, x_pstride;
   int64_t y_nstride, y_pstride;
   int64_t y2_nstride, y2_pstride;
@@ -81,6 +84,13 @@ typedef struct {
                               fp32 partial tiles are summed in a fixed order by a second kernel: deterministic);
                               NULL or too small = no split-K                                              */
   int64_t workspace_bytes;
+  /* Row strides in floats; 0 = dense rows (W resp. Wo pixels apart).  A non-dense row stride is how a tensor
+   * stored with a border of zero pixels is addressed: x / y / res point at interior pixel (0, 0) of image 0. */
+  int64_t x_rstride, y_rstride, res_rstride;
+  int32_t x_border;    /* zero pixels guaranteed around every input image; precision 2 requires >= pad       */
+  int32_t x_format;    /* 0: fp32, 1: SH32 (must be 1 for precision 2, 0 otherwise)                             */
+  int32_t y_format;    /* 0: fp32, 1: SH32 (channels [0, split) only; needs the 16-byte vectorised epilogue)   */
+  int32_t res_format;  /* 0: fp32, 1: SH32                                                                      */
 } mivos_conv_desc;
 
 int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream);
@@ -91,12 +101,31 @@ int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream);
  * kernels walk K (L1/L2 reuse across the taps).  mult must be a power of two.  out: Cout*Kpad*4 bytes. */
 int mivos_pack_weights_f16x3(const float *w, void *out, int Cout, int KH, int KW, int Cin, float mult, void *stream);
 
+/* Pre-split operands for precision 2 (LDS-DMA fed f16x3 GEMM, conv_f16x3_dma.hip).
+ * SH32 activation layout: N x H x W x C, C % 32 == 0; per pixel and group of 32 channels one 128-byte line =
+ * 32 fp16 hi parts then 32 fp16 lo parts (x ~= hi + lo); strides are the fp32 ones (pixel stride C floats).
+ * Precision 2 reads its input with im2col offsets and NO padding masks: every image must be stored with a
+ * border of >= pad zero pixels (x_border), addressed through x_rstride / x_nstride.
+ * mivos_pack_activation_sh32 converts a strided fp32 NHWC tensor into a strided SH32 tensor (e.g. the interior of a
+ * zero-bordered buffer), optionally through ReLU (the consumer cannot apply relu_in on DMA-staged data).
+ * mivos_pack_weights_f16x3_dma: OHWI fp32 -> 128 zero bytes + [K step][Cout][128 B] hi|lo lines, chunk-swizzled
+ * for the LDS image; out must hold mivos_pack_weights_f16x3_dma_bytes(). */
+int mivos_pack_activation_sh32(const float *x, int64_t x_nstride, int64_t x_rstride, int64_t x_pstride, void *y, int64_t y_nstride,
+                               int64_t y_rstride, int64_t y_pstride, int N, int H, int W, int C, int relu, void *stream);
+/* The inverse (x = hi + lo) for consumers outside the convolution path (reference-layout API, tests). */
+int mivos_unpack_activation_sh32(const void *x, int64_t x_nstride, int64_t x_rstride, int64_t x_pstride, float *y, int64_t y_nstride,
+                                 int64_t y_rstride, int64_t y_pstride, int N, int H, int W, int C, void *stream);
+int64_t mivos_pack_weights_f16x3_dma_bytes(int Cout, int KH, int KW, int Cin);
+int mivos_pack_weights_f16x3_dma(const float *w, void *out, int Cout, int KH, int KW, int Cin, float mult, void *stream);
+
 /* Which kernel instantiation mivos_conv2d_fused picks for M = N*Ho*Wo output pixels and Cout channels
  * (0: 128x128 tile, 1: 64x64, 2: 128x32, 3: 128x64, 4: Cout==1 dot product) — for profilers/benchmarks. */
 int mivos_conv2d_variant(int M, int Cout);
 /* Same for precision 1 (f16x3): additionally 5: 256x256 tile / 8 waves pipelined, 6: 128x256 / 8 waves,
  * 7: 128x128 / 8 waves. */
 int mivos_conv2d_variant_f16x3(int M, int Cout);
+/* Same for precision 2 (LDS-DMA ping-pong kernels): 20: 128x128 tile, 21: 128x256, 22: 128x64, 23: 256x256. */
+int mivos_conv2d_variant_pp(int M, int Cout);
 
 /* MaxPool2d(3, stride 2, pad 1) on NHWC (mod_resnet.py:121 / torchvision stem). C % 4 == 0. */
 int mivos_maxpool3x3s2(const float *x, float *y, int N, int H, int W, int C, void *stream);

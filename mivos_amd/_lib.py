@@ -21,7 +21,9 @@ class ConvDesc(C.Structure):
                 ("relu_in", i32), ("relu_out", i32), ("precision", i32),
                 ("x_nstride", i64), ("x_pstride", i64), ("y_nstride", i64), ("y_pstride", i64),
                 ("y2_nstride", i64), ("y2_pstride", i64), ("res_nstride", i64), ("res_pstride", i64),
-                ("workspace", vp), ("workspace_bytes", i64)]
+                ("workspace", vp), ("workspace_bytes", i64),
+                ("x_rstride", i64), ("y_rstride", i64), ("res_rstride", i64),
+                ("x_border", i32), ("x_format", i32), ("y_format", i32), ("res_format", i32)]
 
 
 class InterleaveDesc(C.Structure):
@@ -36,8 +38,13 @@ PROTOTYPES = {
     "mivos_device_check": (C.c_int, [C.c_int]),
     "mivos_conv2d_fused": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "mivos_pack_weights_f16x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "mivos_pack_activation_sh32": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_unpack_activation_sh32": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_pack_weights_f16x3_dma_bytes": (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mivos_pack_weights_f16x3_dma": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "mivos_conv2d_variant": (C.c_int, [C.c_int, C.c_int]),
     "mivos_conv2d_variant_f16x3": (C.c_int, [C.c_int, C.c_int]),
+    "mivos_conv2d_variant_pp": (C.c_int, [C.c_int, C.c_int]),
     "mivos_maxpool3x3s2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_upsample2x_add": (C.c_int, [vp, i64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_memory_read_workspace_bytes": (i64, [C.c_int, i64, C.c_int, C.c_int]),

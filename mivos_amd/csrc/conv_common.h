@@ -13,7 +13,28 @@ struct ConvP {
   float *partial;      // split-K: [slice][M][Cout] fp32 partial sums
   void *ws; long long ws_bytes;
   long long x_ns, x_ps, y_ns, y_ps, y2_ns, y2_ps, r_ns, r_ps;
+  long long x_rs, y_rs, y2_rs, r_rs;   // row strides (floats); dense tensors: W * pixel stride
+  int x_border;                        // zero pixels guaranteed around every input image (precision 2 needs >= pad)
+  int y_fmt, r_fmt;                    // 0: fp32, 1: SH32 (fp16 hi | lo lines per 32 channels, conv_f16x3_dma.hip)
 };
+
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+// SH32 accessors: 4 consecutive channels c..c+3 (c % 4 == 0) of the pixel whose fp32-equivalent float offset is `pix_off`
+__device__ __forceinline__ f32x4 load_sh32x4(const float *base, long long pix_off, int c) {
+  const unsigned char *q = reinterpret_cast<const unsigned char *>(base + pix_off) + (c >> 5) * 128 + (c & 31) * 2;
+  const half4_t hi = *reinterpret_cast<const half4_t *>(q), lo = *reinterpret_cast<const half4_t *>(q + 64);
+  return f32x4{(float)hi.x + (float)lo.x, (float)hi.y + (float)lo.y, (float)hi.z + (float)lo.z, (float)hi.w + (float)lo.w};
+}
+__device__ __forceinline__ void store_sh32x4(float *base, long long pix_off, int c, f32x4 v) {
+  unsigned char *q = reinterpret_cast<unsigned char *>(base + pix_off) + (c >> 5) * 128 + (c & 31) * 2;
+  half4_t hi, lo;
+  hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
+  lo.x = (_Float16)(v.x - (float)hi.x); lo.y = (_Float16)(v.y - (float)hi.y);
+  lo.z = (_Float16)(v.z - (float)hi.z); lo.w = (_Float16)(v.w - (float)hi.w);
+  *reinterpret_cast<half4_t *>(q) = hi;
+  *reinterpret_cast<half4_t *>(q + 64) = lo;
+}
 
 
 // Tile selection shared by the fp32 and the fp16x3 implicit-GEMM kernels.
@@ -46,10 +67,10 @@ __device__ __forceinline__ void epilogue_scalar(const f32x16 (&acc)[MT][NT], con
     const float sc = p.scale ? p.scale[n] : 1.f;
     const float bi = p.bias ? p.bias[n] : 0.f;
     float *dst;
-    long long d_ns, d_ps;
+    long long d_ns, d_rs, d_ps;
     int dn;
-    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_ps = p.y_ps; dn = n; }
-    else { dst = p.y2; d_ns = p.y2_ns; d_ps = p.y2_ps; dn = n - p.split; }
+    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_rs = p.y_rs; d_ps = p.y_ps; dn = n; }
+    else { dst = p.y2; d_ns = p.y2_ns; d_rs = p.y2_rs; d_ps = p.y2_ps; dn = n - p.split; }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -57,10 +78,11 @@ __device__ __forceinline__ void epilogue_scalar(const f32x16 (&acc)[MT][NT], con
         const int m = m_base + i * 32 + mfma32_row(r, lane);
         if (m >= p.M) continue;
         const int img = m / p.HoWo, pix = m - img * p.HoWo;
+        const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
         float v = acc[i][j][r] * sc + bi;
-        if (p.res) v += p.res[(long long)img * p.r_ns + (long long)pix * p.r_ps + n];
+        if (p.res) v += p.res[(long long)img * p.r_ns + (long long)oh * p.r_rs + (long long)ow * p.r_ps + n];
         if (p.relu_out) v = fmaxf(v, 0.f);
-        dst[(long long)img * d_ns + (long long)pix * d_ps + dn] = v;
+        dst[(long long)img * d_ns + (long long)oh * d_rs + (long long)ow * d_ps + dn] = v;
       }
     }
   }
@@ -83,10 +105,10 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float 
     if (nok && p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + n);
     if (nok && p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + n);
     float *dst;
-    long long d_ns, d_ps;
-    int dn;
-    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_ps = p.y_ps; dn = n; }
-    else { dst = p.y2; d_ns = p.y2_ns; d_ps = p.y2_ps; dn = n - p.split; }
+    long long d_ns, d_rs, d_ps;
+    int dn, d_fmt;
+    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_rs = p.y_rs; d_ps = p.y_ps; dn = n; d_fmt = p.y_fmt; }
+    else { dst = p.y2; d_ns = p.y2_ns; d_rs = p.y2_rs; d_ps = p.y2_ps; dn = n - p.split; d_fmt = 0; }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -98,13 +120,17 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float 
         f32x4 v = *reinterpret_cast<const f32x4 *>(scratch + prow * EPI_PITCH + c4);
         if (m < p.M && nok) {
           const int img = m / p.HoWo, pix = m - img * p.HoWo;
+          const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
           v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
           if (p.res) {
-            const f32x4 rr = *reinterpret_cast<const f32x4 *>(p.res + (long long)img * p.r_ns + (long long)pix * p.r_ps + n);
+            const long long ro = (long long)img * p.r_ns + (long long)oh * p.r_rs + (long long)ow * p.r_ps;
+            const f32x4 rr = p.r_fmt ? load_sh32x4(p.res, ro, n) : *reinterpret_cast<const f32x4 *>(p.res + ro + n);
             v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
           }
           if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          *reinterpret_cast<f32x4 *>(dst + (long long)img * d_ns + (long long)pix * d_ps + dn) = v;
+          const long long yo = (long long)img * d_ns + (long long)oh * d_rs + (long long)ow * d_ps;
+          if (d_fmt) store_sh32x4(dst, yo, dn, v);
+          else *reinterpret_cast<f32x4 *>(dst + yo + dn) = v;
         }
       }
     }
@@ -115,5 +141,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float 
 int conv_params_from_desc(const mivos_conv_desc *d, ConvP &p);
 int launch_conv_f16x3(ConvP &p, hipStream_t st);
 int select_variant_f16x3(int M, int Cout);
+int launch_conv_f16x3_dma(ConvP &p, hipStream_t st);
+int launch_splitk_reduce(ConvP &p, int slices, hipStream_t st);   // p.partial [slices][M][Cout] -> y   // precision 2: SH32 input, LDS-DMA staging
 
 }  // namespace mivos

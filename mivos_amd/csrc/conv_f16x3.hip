@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvP p, int kpad4) 
     q.split = p.Cout;
     q.y = p.partial + (long long)blockIdx.y * p.M * p.Cout;
     q.y_ps = p.Cout;
+    q.y_rs = (long long)p.Wo * p.Cout;
     q.y_ns = (long long)p.HoWo * p.Cout;
+    q.y_fmt = 0;
     __syncthreads();
     epilogue_vec<MT, NT>(acc, reinterpret_cast<float *>(smem_raw) + wave * 32 * EPI_PITCH, q, m0 + wm * TM, n0 + wn * TN, lane);
     return;
@@ -821,20 +823,31 @@ __global__ void splitk_reduce_kernel(ConvP p, int n_slices) {
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     const int img = m / p.HoWo, pix = m - img * p.HoWo;
+    const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
     if (p.scale) { const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + n); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
     if (p.bias) { const f32x4 bi = *reinterpret_cast<const f32x4 *>(p.bias + n); v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
     if (p.res) {
-      const f32x4 rr = *reinterpret_cast<const f32x4 *>(p.res + (long long)img * p.r_ns + (long long)pix * p.r_ps + n);
+      const long long ro = (long long)img * p.r_ns + (long long)oh * p.r_rs + (long long)ow * p.r_ps;
+      const f32x4 rr = p.r_fmt ? load_sh32x4(p.res, ro, n) : *reinterpret_cast<const f32x4 *>(p.res + ro + n);
       v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
     }
     if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     float *dst;
-    long long d_ns, d_ps;
-    int dn;
-    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_ps = p.y_ps; dn = n; }
-    else { dst = p.y2; d_ns = p.y2_ns; d_ps = p.y2_ps; dn = n - p.split; }
-    *reinterpret_cast<f32x4 *>(dst + (long long)img * d_ns + (long long)pix * d_ps + dn) = v;
+    long long d_ns, d_rs, d_ps;
+    int dn, d_fmt;
+    if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_rs = p.y_rs; d_ps = p.y_ps; dn = n; d_fmt = p.y_fmt; }
+    else { dst = p.y2; d_ns = p.y2_ns; d_rs = p.y2_rs; d_ps = p.y2_ps; dn = n - p.split; d_fmt = 0; }
+    const long long yo = (long long)img * d_ns + (long long)oh * d_rs + (long long)ow * d_ps;
+    if (d_fmt) store_sh32x4(dst, yo, dn, v);
+    else *reinterpret_cast<f32x4 *>(dst + yo + dn) = v;
   }
+}
+
+int launch_splitk_reduce(ConvP &p, int slices, hipStream_t st) {
+  const long long total = (long long)p.M * (p.Cout / 4);
+  const int blocks = (int)(total / 256 + 1 < 2048 ? total / 256 + 1 : 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, slices);
+  return check_launch("splitk_reduce");
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -862,11 +875,7 @@ static int launch_f16x3(ConvP &p, hipStream_t st) {
   }
   const int kpad4 = cdiv(p.Ktot, BKH) * BKH / 4;
   hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n, slices), dim3(256), lds, st, p, kpad4);
-  if (slices > 1) {
-    const long long total = (long long)p.M * (p.Cout / 4);
-    const int blocks = (int)(total / 256 + 1 < 2048 ? total / 256 + 1 : 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, slices);
-  }
+  if (slices > 1) return launch_splitk_reduce(p, slices, st);
   return check_launch("conv_f16x3");
 }
 

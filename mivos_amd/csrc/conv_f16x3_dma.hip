@@ -1,0 +1,422 @@
+// f16x3 implicit-GEMM convolution fed by LDS-DMA from PRE-SPLIT, ZERO-BORDERED operands (precision 2).
+//
+// What bounds the register-staged kernel (conv_f16x3.hip) - measured, scripts/ubench/lds_vs_mfma.hip:
+// while one wave of a SIMD streams MFMAs back to back, its partner wave gets ONE vector-ALU instruction
+// issued per MFMA (~40 cycles each), although ds_read_b128, scalar ALU and LDS-DMA issue at full speed.
+// Splitting fp32 activations into fp16 (hi, lo) during staging, im2col address arithmetic and padding
+// masks are a few hundred VALU instructions per wave and K step: they, not the matrix pipe, LDS or L2
+// (33 TB/s measured for LDS-DMA), set the pace (MFMA pipe 35 % busy).  This kernel has NO vector-ALU
+// instruction in its main loop:
+//   * activations arrive already split ("SH32": per pixel and 32 channels one 128-byte line = 32 fp16 hi |
+//     32 fp16 lo, same 4 bytes per element as fp32, written by the producer's epilogue);
+//   * their storage has a border of zero pixels >= the conv padding, so im2col needs no masks: the source
+//     of every LDS-DMA piece is  constant per-lane byte offset (VGPR)  +  per-step tap/slab offset (SGPR,
+//     scalar ALU)  in one buffer_load_dwordx4 ... offen lds;  tile rows past M / columns past Cout carry
+//     an out-of-range offset and the buffer unit returns zeros for them;
+//   * weights are packed as [K step][Cout][128 B] hi|lo lines, pre-swizzled for the LDS image;
+//   * fragment reads use per-lane base addresses computed once + immediate offsets (K loop unrolled x6 so
+//     that the 3-deep activation ring and the 2-deep weight ring are addressed by constants).
+//
+// LDS image per stage: rows x 128 B, chunk c (16 B) of row r at chunk position c ^ ((r >> 1) & 7).  LDS-DMA
+// writes lane-linear (8 rows x 128 B per wave instruction), so the swizzle is applied to the SOURCE offset
+// (cdna guide rule 21); every ds_read_b128 lane group {0-3,12-15,20-27}, ... of a fragment read then covers all
+// sixteen 16-byte slots of the 256-byte bank row: conflict-free.
+//
+// Ping-pong schedule (cdna guide "256^2 8-phase template" adapted to the 3-product f16x3 step): waves 0-3
+// (group G0) and 4-7 (G1) sit one per SIMD each.  A wave alternates LOAD phases (all fragments of one
+// 16-deep half step by ds_read_b128 + a few LDS-DMA pieces, ~600 cycles) and MFMA phases (MT*NT*3 back-to-back
+// MFMAs on register-resident fragments), separated by workgroup barriers; G1 runs one barrier behind G0,
+// so each SIMD always has one wave inside an MFMA phase:
+//   G0:  L(t,0) | M(t,0) | L(t,1) | M(t,1) | L(t+1,0) ...
+//   G1:         | L(t,0) | M(t,0) | L(t,1) | M(t,1)   ...
+//   L(t,0) issues the weight pieces of step t+1 (ring of 2 stages; L2 hits),
+//   L(t,1) issues the activation pieces of step t+2 (ring of 3: first touches come from HBM) and ends with
+//   vmcnt(#those pieces): everything older - all operands of step t+1 - has landed before the barrier that
+//   every reader of step t+1 passes first.  A stage is overwritten no earlier than one step after its last
+//   reader retired its ds_reads (lgkmcnt(0) before each barrier).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace mivos {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+constexpr int ROWB = 128;   // bytes per tile row and K step: 32 k x (hi, lo) fp16
+constexpr unsigned OOB_OFFSET = 0x80000000u;   // + any step offset stays >= num_records (< 2 GB) without wrapping
+
+template <int BM, int BN, int WGM, int WGN, int ABL = 0>   // ABL: profiling ablations (1: no DMA, 2: no DMA wait, 3: no fragment reads)
+__global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_bytes, unsigned w_bytes) {
+  static_assert(WGM * WGN == 8, "8 waves per workgroup");
+  static_assert(BM % 64 == 0 && BN % 64 == 0, "tile rows are fetched 64 at a time");
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int MT = TM / 32, NT = TN / 32;
+  constexpr int A_LD = BM / 64, B_LD = BN / 64;        // DMA pieces per wave and step
+  constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * ROWB, B_BASE = 3 * A_STAGE;
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in the device pass only; the host pass just needs the stub
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
+  const int ntaps = p.KH * p.KW;
+
+  // buffer resources: activations from the first border pixel of image 0, weights from their zero line
+  const unsigned char *x_lo = reinterpret_cast<const unsigned char *>(p.x) - ((long long)p.pad * p.x_rs + (long long)p.pad * p.x_ps) * 4;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)x_lo, 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, w_bytes, 0x00020000);
+
+  const int lrow = lane >> 3, pch = lane & 7;
+  // rows this lane fetches: r = (j * 8 + wave) * 8 + lrow  =>  (r >> 1) & 7 = 4 * (wave & 1) + (lrow >> 1)
+  const int src_chunk = (pch ^ (4 * (wave & 1) + (lrow >> 1))) * 16;
+  unsigned voff_a[A_LD], voff_b[B_LD];
+#pragma unroll
+  for (int j = 0; j < A_LD; ++j) {
+    const int m = m0 + (j * 8 + wave) * 8 + lrow;
+    const int mm = m < p.M ? m : 0;
+    const int n = mm / p.HoWo, rem = mm - n * p.HoWo;
+    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+    const long long off = ((long long)n * p.x_ns + (long long)oh * p.stride * p.x_rs + (long long)ow * p.stride * p.x_ps) * 4 + src_chunk;
+    voff_a[j] = m < p.M ? (unsigned)off : OOB_OFFSET;
+  }
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int n = n0 + (j * 8 + wave) * 8 + lrow;
+    voff_b[j] = n < p.Cout ? (unsigned)(ROWB + n * ROWB + pch * 16) : OOB_OFFSET;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // ---- LDS-DMA issue: scalar state only --------------------------------------------------------------
+  const int lds0 = __builtin_amdgcn_readfirstlane((int)(size_t)smem) + wave * 1024;
+  const int pix_step = (int)(p.x_ps * 4);
+  const int row_step = (int)(p.x_rs * 4) - p.KW * pix_step;             // from behind the last tap of a row to the next row
+  // split-K (small-M layers): gridDim.y slices of kt_split K steps each; raw partial tiles go to p.partial
+  const int nk_all = (p.Cin >> 5) * ntaps;
+  const int kt0 = p.kt_split ? (int)blockIdx.y * p.kt_split : 0;
+  const int nk = (p.kt_split && kt0 + p.kt_split < nk_all ? kt0 + p.kt_split : nk_all) - kt0;      // steps of this slice
+  const int b_step = p.Cout * ROWB;
+  int a_tap = kt0 % ntaps, a_kw = a_tap % p.KW;                         // activation stream: tap / slab of its next step
+  int a_tap_off = ((a_tap / p.KW) * (int)(p.x_rs * 4)) + a_kw * pix_step, a_slab_off = (kt0 / ntaps) * ROWB;
+  int b_off = kt0 * b_step;                                             // weight stream: byte offset of its next step
+  auto issue_a = [&](int stage) {
+    const int soff = a_tap_off + a_slab_off;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(size_t)(lds0 + stage * A_STAGE + j * 8192), 16, voff_a[j], soff, 0, 0);
+    a_tap_off += pix_step;
+    if (++a_kw == p.KW) { a_kw = 0; a_tap_off += row_step; }
+    if (++a_tap == ntaps) { a_tap = 0; a_tap_off = 0; a_slab_off += ROWB; }
+  };
+  auto issue_b = [&](int stage) {
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(size_t)(lds0 + B_BASE + stage * B_STAGE + j * 8192), 16, voff_b[j], b_off, 0, 0);
+    b_off += b_step;
+  };
+
+  // ---- fragment addressing: per-lane bases once, stages / tiles by immediates ---------------------------
+  // row = tile row of the wave + (lane & 31); logical chunk = part * 4 + kk * 2 + (lane >> 5), XOR ((row >> 1) & 7)
+  const int swz = (lane >> 1) & 7;
+  const unsigned char *fa[2][2], *fb[2][2];
+#pragma unroll
+  for (int part = 0; part < 2; ++part)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int fo = ((part * 4 + kk * 2 + (lane >> 5)) ^ swz) * 16;
+      fa[part][kk] = smem + (wm * TM + (lane & 31)) * ROWB + fo;
+      fb[part][kk] = smem + B_BASE + (wn * TN + (lane & 31)) * ROWB + fo;
+    }
+
+  h8 ah[MT], al[MT], bh[NT], bl[NT];
+  auto load_frags = [&](int sa, int sb, int kk) {
+    if (ABL == 3) return;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bh[j] = *reinterpret_cast<const h8 *>(fb[0][kk] + sb * B_STAGE + j * 32 * ROWB);
+      bl[j] = *reinterpret_cast<const h8 *>(fb[1][kk] + sb * B_STAGE + j * 32 * ROWB);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      ah[i] = *reinterpret_cast<const h8 *>(fa[0][kk] + sa * A_STAGE + i * 32 * ROWB);
+      al[i] = *reinterpret_cast<const h8 *>(fa[1][kk] + sa * A_STAGE + i * 32 * ROWB);
+    }
+  };
+  // per accumulator the three products keep the order of conv_f16x3.hip (lo*hi, hi*lo, hi*hi): bit-identical sums
+  auto mfma_phase = [&]() {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+  };
+  auto phase_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // one K step; U = kt % 6 is a compile-time constant => ring positions kt % 3 / kt % 2 are immediates.
+  // TAIL = false: steady state (both prefetches exist), no scalar branches inside the step.
+  auto step = [&](int kt, auto u_tag, auto tail_tag) {
+    constexpr int U = decltype(u_tag)::value;
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    constexpr int sa = U % 3, sb = U % 2;
+    load_frags(sa, sb, 0);                                     // L(kt, 0)
+    if (ABL != 1 && (!TAIL || kt + 1 < nk)) issue_b(sb ^ 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    phase_barrier();
+    mfma_phase();                                              // M(kt, 0)
+    phase_barrier();
+    load_frags(sa, sb, 1);                                     // L(kt, 1)
+    if (ABL == 1 || ABL == 2) {
+      if (ABL == 2 && (!TAIL || kt + 2 < nk)) issue_a((sa + 2) % 3);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (!TAIL || kt + 2 < nk) {
+      issue_a((sa + 2) % 3);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(A_LD) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    phase_barrier();
+    mfma_phase();                                              // M(kt, 1)
+    phase_barrier();
+  };
+  using std::integral_constant;
+  typedef std::false_type steady;
+  typedef std::true_type tail;
+
+  issue_a(0);
+  if (ABL != 1) issue_b(0);
+  if (nk > 1) issue_a(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  phase_barrier();                       // step 0 (and the activations of step 1) landed for everybody
+  if (wave >= 4) phase_barrier();        // G1 runs one phase behind
+  int kt = 0;
+  for (; kt + 8 <= nk; kt += 6) {        // every step of the group still has its two prefetches
+    step(kt, integral_constant<int, 0>{}, steady{});
+    step(kt + 1, integral_constant<int, 1>{}, steady{});
+    step(kt + 2, integral_constant<int, 2>{}, steady{});
+    step(kt + 3, integral_constant<int, 3>{}, steady{});
+    step(kt + 4, integral_constant<int, 4>{}, steady{});
+    step(kt + 5, integral_constant<int, 5>{}, steady{});
+  }
+  for (; kt < nk; kt += 6) {
+    step(kt, integral_constant<int, 0>{}, tail{});
+    if (kt + 1 < nk) step(kt + 1, integral_constant<int, 1>{}, tail{});
+    if (kt + 2 < nk) step(kt + 2, integral_constant<int, 2>{}, tail{});
+    if (kt + 3 < nk) step(kt + 3, integral_constant<int, 3>{}, tail{});
+    if (kt + 4 < nk) step(kt + 4, integral_constant<int, 4>{}, tail{});
+    if (kt + 5 < nk) step(kt + 5, integral_constant<int, 5>{}, tail{});
+  }
+  if (wave < 4) phase_barrier();         // G0 waits for G1's last phase; the LDS stages are dead after this
+  if (p.kt_split) {                      // raw fp32 partial tile of this K slice: [slice][M][Cout], dense
+    ConvP q = p;
+    q.scale = q.bias = q.res = nullptr;
+    q.relu_out = 0;
+    q.split = p.Cout;
+    q.y = p.partial + (long long)blockIdx.y * p.M * p.Cout;
+    q.y_ps = p.Cout; q.y_rs = (long long)p.Wo * p.Cout; q.y_ns = (long long)p.HoWo * p.Cout; q.y_fmt = 0;
+    epilogue_vec<MT, NT>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, q, m0 + wm * TM, n0 + wn * TN, lane);
+    return;
+  }
+  if (p.vec_epi) epilogue_vec<MT, NT>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
+  else epilogue_scalar<MT, NT>(acc, p, m0 + wm * TM, n0 + wn * TN, lane);
+#endif
+}
+
+// fp32 NHWC (strided) -> SH32 (strided, e.g. the interior of a zero-bordered buffer), optionally through ReLU
+__global__ void pack_activation_sh32_kernel(const float *__restrict__ x, long long x_ns, long long x_rs, long long x_ps,
+                                            unsigned char *__restrict__ y, long long y_ns, long long y_rs, long long y_ps, int N, int H, int W,
+                                            int C, int relu) {
+  const int c8n = C >> 3;
+  const long long total = (long long)N * H * W * c8n;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    long long pix = e / c8n;
+    const int c = (int)(e - pix * c8n) * 8;
+    const int n = (int)(pix / ((long long)H * W));
+    pix -= (long long)n * H * W;
+    const int h = (int)(pix / W), w = (int)(pix - (long long)h * W);
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(x + n * x_ns + h * x_rs + w * x_ps + c);
+    const f32x4 v0 = src[0], v1 = src[1];
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    h8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float t = relu ? fmaxf(v[i], 0.f) : v[i];
+      hi[i] = (_Float16)t;
+      lo[i] = (_Float16)__builtin_fmaf((float)hi[i], -1.f, t);
+    }
+    unsigned char *dst = y + (n * y_ns + h * y_rs + w * y_ps) * 4 + (c >> 5) * ROWB + (c & 31) * 2;
+    *reinterpret_cast<h8 *>(dst) = hi;
+    *reinterpret_cast<h8 *>(dst + 64) = lo;
+  }
+}
+
+// SH32 (strided) -> fp32 NHWC (strided): x = hi + lo
+__global__ void unpack_activation_sh32_kernel(const unsigned char *__restrict__ x, long long x_ns, long long x_rs, long long x_ps,
+                                              float *__restrict__ y, long long y_ns, long long y_rs, long long y_ps, int N, int H, int W, int C) {
+  const int c8n = C >> 3;
+  const long long total = (long long)N * H * W * c8n;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    long long pix = e / c8n;
+    const int c = (int)(e - pix * c8n) * 8;
+    const int n = (int)(pix / ((long long)H * W));
+    pix -= (long long)n * H * W;
+    const int h = (int)(pix / W), w = (int)(pix - (long long)h * W);
+    const unsigned char *src = x + (n * x_ns + h * x_rs + w * x_ps) * 4 + (c >> 5) * ROWB + (c & 31) * 2;
+    const h8 hi = *reinterpret_cast<const h8 *>(src), lo = *reinterpret_cast<const h8 *>(src + 64);
+    f32x4 v0, v1;
+    v0.x = (float)hi[0] + (float)lo[0]; v0.y = (float)hi[1] + (float)lo[1]; v0.z = (float)hi[2] + (float)lo[2]; v0.w = (float)hi[3] + (float)lo[3];
+    v1.x = (float)hi[4] + (float)lo[4]; v1.y = (float)hi[5] + (float)lo[5]; v1.z = (float)hi[6] + (float)lo[6]; v1.w = (float)hi[7] + (float)lo[7];
+    f32x4 *dst = reinterpret_cast<f32x4 *>(y + n * y_ns + h * y_rs + w * y_ps + c);
+    dst[0] = v0;
+    dst[1] = v1;
+  }
+}
+
+__global__ void pack_weights_dma_kernel(const float *__restrict__ w, unsigned char *__restrict__ out, int Cout, int cin,
+                                        int ntaps, float mult) {
+  const int nsteps = (cin >> 5) * ntaps;
+  const long long total = (long long)nsteps * Cout * 8;
+  if (blockIdx.x == 0 && threadIdx.x < 32) reinterpret_cast<float *>(out)[threadIdx.x] = 0.f;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(e & 7);                          // physical chunk
+    const long long row = e >> 3;                        // s * Cout + n
+    const int s = (int)(row / Cout), n = (int)(row - (long long)s * Cout);
+    const int lc = q ^ ((n >> 1) & 7), part = lc >> 2, k0 = (lc & 3) * 8;
+    const int slab = s / ntaps, tap = s - slab * ntaps;
+    h8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v = w[((long long)n * ntaps + tap) * cin + slab * 32 + k0 + i] * mult;
+      const _Float16 hi = (_Float16)v;
+      o[i] = part ? (_Float16)(v - (float)hi) : hi;
+    }
+    *reinterpret_cast<h8 *>(out + ROWB + row * ROWB + q * 16) = o;
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int ABL = 0>
+static int launch_pp(ConvP &p, hipStream_t st) {
+  const int tiles_m = cdiv(p.M, BM);
+  p.tiles_n = cdiv(p.Cout, BN);
+  const size_t lds = (3ull * BM + 2ull * BN) * ROWB;
+  auto kern = conv_f16x3_pp_kernel<BM, BN, WGM, WGN, ABL>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(conv_f16x3_pp): %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const long long x_bytes = ((long long)(p.N - 1) * p.x_ns + (long long)(p.H + 2 * p.pad - 1) * p.x_rs + (long long)(p.W + 2 * p.pad) * p.x_ps) * 4;
+  const long long w_bytes = ROWB + (long long)(p.Cin >> 5) * p.KH * p.KW * p.Cout * ROWB;
+  if (x_bytes >= 0x7ff00000ll || w_bytes >= 0x7ff00000ll) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d (SH32 input): tensor larger than 2 GB");
+  // split-K when the tile grid cannot fill the chip and K is long (30x54 layers at small batch)
+  const int nk = (p.Cin >> 5) * p.KH * p.KW, wgs = tiles_m * p.tiles_n, cap = lds <= 80 * 1024 ? 512 : 256;
+  int slices = 1;
+  if (p.vec_epi && p.ws && wgs * 3 <= cap && nk >= 16) {
+    slices = cap / wgs;
+    if (slices > 8) slices = 8;
+    if (slices > nk / 8) slices = nk / 8;
+    if ((long long)slices * p.M * p.Cout * 4 > p.ws_bytes) slices = 1;
+  }
+  p.kt_split = 0;
+  if (slices > 1) { p.kt_split = cdiv(nk, slices); slices = cdiv(nk, p.kt_split); p.partial = (float *)p.ws; }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n, slices), dim3(512), lds, st, p, (unsigned)x_bytes, (unsigned)w_bytes);
+  if (slices > 1) return launch_splitk_reduce(p, slices, st);
+  return check_launch("conv_f16x3_pp");
+}
+
+// Tile selection for precision 2.  20: 128x128 (80 KB LDS: two workgroups per CU overlap each other's barrier
+// bubbles; the robust default), 21: 128x256 (one workgroup per CU; wins when its tiles fill whole rounds of the
+// 256 CUs), 22: 128x64 (Cout <= 64), 23: 256x256 (profiling only: equal to 20 on its best shapes).
+int select_variant_pp(int M, int Cout) {
+  if (Cout <= 64) return 22;
+  if (Cout % 256 == 0) {
+    const long long t = (long long)cdiv(M, 128) * (Cout / 256);
+    const long long rounds = (t + 255) / 256;
+    if (t >= 200 && (double)t / (double)(rounds * 256) >= 0.85) return 21;
+  }
+  return 20;
+}
+
+int launch_conv_f16x3_dma(ConvP &p, hipStream_t st) {
+  if (p.Cin & 31) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d (SH32 input): Cin %% 32 != 0");
+  if (p.relu_in) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d (SH32 input): relu_in must be applied by the producer");
+  if ((p.x_ps & 31) || (p.x_ns & 31) || (p.x_rs & 31)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d (SH32 input): strides must be multiples of 32");
+  if (p.x_border < p.pad) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d (SH32 input): needs a zero border >= pad around every image");
+  static const int force = getenv("MIVOS_PP_TILE") ? atoi(getenv("MIVOS_PP_TILE")) : 0;   // tuning only
+  switch (force ? force : select_variant_pp(p.M, p.Cout)) {
+    case 23: {
+      static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;   // profiling only
+      if (abl == 1) return launch_pp<256, 256, 2, 4, 1>(p, st);
+      if (abl == 2) return launch_pp<256, 256, 2, 4, 2>(p, st);
+      if (abl == 3) return launch_pp<256, 256, 2, 4, 3>(p, st);
+      return launch_pp<256, 256, 2, 4>(p, st);
+    }
+    case 21: return launch_pp<128, 256, 2, 4>(p, st);
+    case 22: return launch_pp<128, 64, 4, 2>(p, st);
+    default: return launch_pp<128, 128, 2, 4>(p, st);
+  }
+}
+
+}  // namespace mivos
+
+using namespace mivos;
+
+extern "C" int mivos_conv2d_variant_pp(int M, int Cout) { return select_variant_pp(M, Cout); }
+
+extern "C" int mivos_pack_activation_sh32(const float *x, int64_t x_nstride, int64_t x_rstride, int64_t x_pstride, void *y, int64_t y_nstride,
+                                           int64_t y_rstride, int64_t y_pstride, int N, int H, int W, int C, int relu, void *stream) {
+  if (!x || !y || N < 1 || H < 1 || W < 1 || C < 32 || (C & 31) || ((x_pstride | x_rstride | x_nstride) & 3) || ((y_pstride | y_rstride | y_nstride) & 31) ||
+      ((uintptr_t)x & 15) || ((uintptr_t)y & 127))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "pack_activation_sh32: bad arguments");
+  const long long total = (long long)N * H * W * (C >> 3);
+  const int blocks = (int)(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
+  hipLaunchKernelGGL(pack_activation_sh32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)x_nstride, (long long)x_rstride,
+                     (long long)x_pstride, (unsigned char *)y, (long long)y_nstride, (long long)y_rstride, (long long)y_pstride, N, H, W, C, relu);
+  return check_launch("pack_activation_sh32");
+}
+
+extern "C" int mivos_unpack_activation_sh32(const void *x, int64_t x_nstride, int64_t x_rstride, int64_t x_pstride, float *y, int64_t y_nstride,
+                                             int64_t y_rstride, int64_t y_pstride, int N, int H, int W, int C, void *stream) {
+  if (!x || !y || N < 1 || H < 1 || W < 1 || C < 32 || (C & 31) || ((y_pstride | y_rstride | y_nstride) & 3) || ((x_pstride | x_rstride | x_nstride) & 31) ||
+      ((uintptr_t)y & 15) || ((uintptr_t)x & 127))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "unpack_activation_sh32: bad arguments");
+  const long long total = (long long)N * H * W * (C >> 3);
+  const int blocks = (int)(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
+  hipLaunchKernelGGL(unpack_activation_sh32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char *)x, (long long)x_nstride,
+                     (long long)x_rstride, (long long)x_pstride, y, (long long)y_nstride, (long long)y_rstride, (long long)y_pstride, N, H, W, C);
+  return check_launch("unpack_activation_sh32");
+}
+
+extern "C" int64_t mivos_pack_weights_f16x3_dma_bytes(int Cout, int KH, int KW, int Cin) {
+  return 128 + (int64_t)(Cin >> 5) * KH * KW * Cout * 128;
+}
+
+extern "C" int mivos_pack_weights_f16x3_dma(const float *w, void *out, int Cout, int KH, int KW, int Cin, float mult, void *stream) {
+  if (!w || !out || Cout < 1 || Cin < 32 || (Cin & 31) || KH < 1 || KW < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "pack_weights_f16x3_dma: bad arguments");
+  const long long total = (long long)(Cin >> 5) * KH * KW * Cout * 8;
+  const int blocks = (int)(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
+  hipLaunchKernelGGL(pack_weights_dma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char *)out, Cout, Cin, KH * KW, mult);
+  return check_launch("pack_weights_f16x3_dma");
+}

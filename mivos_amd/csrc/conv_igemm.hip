@@ -229,9 +229,22 @@ int conv_params_from_desc(const mivos_conv_desc *d, ConvP &p) {
   p.x_ns = d->x_nstride; p.x_ps = d->x_pstride; p.y_ns = d->y_nstride; p.y_ps = d->y_pstride;
   p.y2_ns = d->y2_nstride; p.y2_ps = d->y2_pstride; p.r_ns = d->res_nstride; p.r_ps = d->res_pstride;
   p.kt_split = 0; p.partial = nullptr; p.ws = d->workspace; p.ws_bytes = d->workspace_bytes;
+  p.x_rs = d->x_rstride ? d->x_rstride : (long long)d->W * d->x_pstride;
+  p.y_rs = d->y_rstride ? d->y_rstride : (long long)d->Wo * d->y_pstride;
+  p.y2_rs = (long long)d->Wo * d->y2_pstride;
+  p.r_rs = d->res_rstride ? d->res_rstride : (long long)d->Wo * d->res_pstride;
+  p.x_border = d->x_border; p.y_fmt = d->y_format; p.r_fmt = d->res_format;
+  if ((d->x_format != 0) != (d->precision == 2)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: x_format 1 (SH32) goes with precision 2 and only with it");
+  if (d->precision != 2 && p.x_rs != (long long)d->W * d->x_pstride) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: precision 0/1 read dense input rows");
+  if (d->precision != 2 && (p.y_rs != (long long)d->Wo * d->y_pstride || (d->res && p.r_rs != (long long)d->Wo * d->res_pstride)))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: precision 0/1 write / add dense rows");
+  if ((p.y_rs | p.r_rs | p.x_rs) & 3) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: row strides %% 4 != 0");
   auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
   p.vec_epi = !(p.Cout & 3) && !(p.split & 3) && !((p.y_ns | p.y_ps) & 3) && al16(p.y) && al16(p.scale) && al16(p.bias) &&
               (!dual || (!((p.y2_ns | p.y2_ps) & 3) && al16(p.y2))) && (!p.res || (!((p.r_ns | p.r_ps) & 3) && al16(p.res)));
+  if ((p.y_fmt || p.r_fmt) && (!p.vec_epi || (p.split & 31) || ((p.y_ps | p.y_rs | p.y_ns) & 31 && p.y_fmt) || (p.r_fmt && ((p.r_ps | p.r_rs | p.r_ns) & 31))))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: SH32 output / residual needs 32-channel groups, strides %% 32 == 0 and 16-byte aligned operands");
+  if ((p.y_fmt || p.r_fmt) && d->precision != 2) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: SH32 output / residual is implemented by the precision-2 kernels only");
   return MIVOS_OK;
 }
 }  // namespace mivos
@@ -241,6 +254,7 @@ extern "C" int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream) {
   int rc = conv_params_from_desc(d, p);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (d->precision == 2) return launch_conv_f16x3_dma(p, st);
   if (d->precision == 1 && p.Cout > 1) return launch_conv_f16x3(p, st);
 
   if (p.Cout == 1) {

@@ -72,8 +72,15 @@ class Bottleneck(nn.Module):
         return (self.conv1.pack(self.bn1), self.conv2.pack(self.bn2), self.conv3.pack(self.bn3), ds)
 
 
-def run_bottleneck(plan, x):
+def run_bottleneck(plan, x, tag=None):
+    """x: fp32 NHWC tensor (register-staged kernels) or ops.Act (LDS-DMA kernels: intermediates live in scratch Acts, the
+    block output in the scratch Act `tag`, or in fresh storage when tag is None)."""
     c1, c2, c3, ds = plan
+    if isinstance(x, ops.Act):
+        t = ops.conv(x, c1, relu_out=True, out_act=True, tag="bneck.1")
+        t = ops.conv(t, c2, relu_out=True, out_act=True, tag="bneck.2")
+        idt = x if ds is None else ops.conv(x, ds, out_act=True, tag="bneck.ds")
+        return ops.conv(t, c3, res=idt, relu_out=True, out_act=True, tag=tag)
     t = ops.conv(x, c1, relu_out=True)
     t = ops.conv(t, c2, relu_out=True)
     idt = x if ds is None else ops.conv(x, ds)
@@ -104,14 +111,19 @@ class _Trunk(nn.Module):
         return (self.conv1.pack(self.bn1, cin_pad=cin_pad), stages)
 
 
-def run_trunk(plan, x):
-    """x NHWC [N,H,W,4|8] -> (f16, f8, f4)."""
+def run_trunk(plan, x, keep=True):
+    """x NHWC [N,H,W,4|8] -> (f16, f8, f4).  With the f16x3 back-end everything behind the stem runs on the LDS-DMA
+    kernels and the features are ops.Act (SH32, zero-bordered); keep=False puts them into scratch storage too (the
+    caller consumes them before the next trunk call)."""
     stem, stages = plan
     x = ops.maxpool3x3s2(ops.conv(x, stem, relu_out=True))
+    if ops.act_path():
+        x = ops.to_act(x, tag="trunk.stem")
     feats = []
     for stage in stages:
-        for blk in stage:
-            x = run_bottleneck(blk, x)
+        for i, blk in enumerate(stage):
+            last = i == len(stage) - 1
+            x = run_bottleneck(blk, x, tag=None if (last and keep) else ("bneck.out", i & 1))
         feats.append(x)
     return feats[2], feats[1], feats[0]
 
@@ -158,10 +170,16 @@ class ResBlock(nn.Module):
 
 
 def run_resblock(plan, x):
+    """x fp32 NHWC -> fp32 NHWC: x(+ds) + conv2(relu(conv1(relu(x)))).  On the LDS-DMA path the two ReLUs move to the
+    producers (the pack of x and the epilogue of conv1): a DMA-staged operand cannot be modified on load."""
     c1, c2, ds = plan
+    if ops.act_path() and c1.cin % 32 == 0:
+        r = ops.conv(ops.to_act(x, relu=True, tag="resblock.in"), c1, relu_out=True, out_act=True, tag="resblock.mid")
+        skip = x if ds is None else ops.conv(ops.to_act(x, tag="resblock.raw"), ds)
+        return ops.conv(r, c2, res=skip)
     r = ops.conv(x, c1, relu_in=True)
     skip = x if ds is None else ops.conv(x, ds)
-    return ops.conv(r, c2, relu_in=True, res=skip)       # x(+ds) + conv2(relu(conv1(relu(x))))
+    return ops.conv(r, c2, relu_in=True, res=skip)
 
 
 class UpsampleBlock(nn.Module):

@@ -79,7 +79,8 @@ class QueryFeatures:
         self.s8 = self.s4 = None
 
     def as_reference_tuple(self):
-        return tuple(t.permute(0, 3, 1, 2) for t in (self.f16, self.f8, self.f4, self.k16, self.v16))
+        dense = [ops.to_f32(t) if isinstance(t, ops.Act) else t for t in (self.f16, self.f8, self.f4, self.k16, self.v16)]
+        return tuple(t.permute(0, 3, 1, 2) for t in dense)
 
 
 def _nhwc(t):
@@ -175,7 +176,7 @@ class PropagationNetwork(nn.Module):
         P = H * W
         planes = [(frame[0, c], 0) for c in range(3)] + [(masks, P), (others, P)]
         x = ops.interleave(planes, K, P, 8, frame.device).view(K, H, W, 8)
-        f16, _, _ = run_trunk(p["menc"], x)
+        f16, _, _ = run_trunk(p["menc"], x, keep=False)
         return ops.conv(f16, p["kv_m"], out=key_out, out2=val_out)
 
     def segment(self, keys, values, q, logits=False):
@@ -210,7 +211,10 @@ class PropagationNetwork(nn.Module):
 
     def segment_with_query(self, keys, values, f16, f8, f4, k16, v16):
         K, _, T, h, w = keys.shape
-        q = QueryFeatures(*(_nhwc(t) for t in (f16, f8, f4, k16, v16)))
+        feats = [_nhwc(t) for t in (f16, f8, f4)]
+        if ops.act_path():
+            feats = [ops.to_act(t) for t in feats]
+        q = QueryFeatures(*feats, _nhwc(k16), _nhwc(v16))
         kr = keys.permute(0, 2, 3, 4, 1).reshape(K, T * h * w, CK)
         vr = values.permute(0, 2, 3, 4, 1).reshape(K, T * h * w, CV)
         prob = self.segment(kr, vr, q)

@@ -54,7 +54,7 @@ def _nhwc_strides(t):
 
 class ConvLayer:
     """Device-resident packed convolution: OHWI weights (+ folded BN scale / bias)."""
-    __slots__ = ("w", "scale", "bias", "cin", "cout", "k", "stride", "pad", "split", "w16", "scale16")
+    __slots__ = ("w", "scale", "bias", "cin", "cout", "k", "stride", "pad", "split", "w16", "scale16", "wdma")
 
     def __init__(self, w_ohwi, scale, bias, stride, pad, split=None):
         self.w = w_ohwi.contiguous()
@@ -62,23 +62,41 @@ class ConvLayer:
         self.scale, self.bias = scale, bias
         self.stride, self.pad = stride, pad
         self.split = self.cout if split is None else split
-        self.w16 = self.scale16 = None
+        self.w16 = self.scale16 = self.wdma = None
+
+    def _f16x3_scale(self):
+        """(2^s, scale * 2^-s): the exact power-of-two pre-scaling of the fp16 hi/lo weight split."""
+        import math
+        wmax = float(self.w.abs().max())
+        s = 14 - math.floor(math.log2(wmax)) if wmax > 0 else 0     # max |w * 2^s| in [2^14, 2^15)
+        mult = 2.0 ** s
+        base = self.scale if self.scale is not None else torch.ones(self.cout, dtype=torch.float32, device=self.w.device)
+        return mult, (base * (1.0 / mult)).contiguous()
+
+    def dma(self):
+        """(weights packed for the LDS-DMA kernels (precision 2), epilogue scale); needs cin % 32 == 0."""
+        if self.wdma is None:
+            _ensure_device(self.w)
+            lib = _lib.load()
+            mult, scale16 = self._f16x3_scale()
+            wd = torch.empty(lib.mivos_pack_weights_f16x3_dma_bytes(self.cout, self.k, self.k, self.cin), dtype=torch.uint8, device=self.w.device)
+            check(lib.mivos_pack_weights_f16x3_dma(self.w.data_ptr(), wd.data_ptr(), self.cout, self.k, self.k, self.cin, mult, _stream()))
+            self.wdma = wd
+            if self.scale16 is None:
+                self.scale16 = scale16
+        return self.wdma, self.scale16
 
     def f16x3(self):
         """(packed hi/lo fp16 weights, epilogue scale incl. the 2^-s of the weight pre-scaling); built on
         first use on the GPU the layer lives on."""
         if self.w16 is None:
-            import math
             _ensure_device(self.w)
             ktot = self.k * self.k * self.cin
             kpad = (ktot + 63) // 64 * 64
-            wmax = float(self.w.abs().max())
-            s = 14 - math.floor(math.log2(wmax)) if wmax > 0 else 0     # max |w * 2^s| in [2^14, 2^15)
-            mult = 2.0 ** s
+            mult, scale16 = self._f16x3_scale()
             w16 = torch.empty(self.cout * kpad * 4, dtype=torch.uint8, device=self.w.device)
             check(_lib.load().mivos_pack_weights_f16x3(self.w.data_ptr(), w16.data_ptr(), self.cout, self.k, self.k, self.cin, mult, _stream()))
-            base = self.scale if self.scale is not None else torch.ones(self.cout, dtype=torch.float32, device=self.w.device)
-            self.w16, self.scale16 = w16, (base * (1.0 / mult)).contiguous()
+            self.w16, self.scale16 = w16, scale16
         return self.w16, self.scale16
 
     @staticmethod
@@ -112,49 +130,149 @@ class ConvLayer:
             v = getattr(self, n)
             if v is not None:
                 setattr(self, n, v.to(device))
-        self.w16 = self.scale16 = None
+        self.w16 = self.scale16 = self.wdma = None
         return self
 
 
-def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None):
-    """y = act(conv(act_in(x)) * scale + bias + res).  x [N,H,W,Cin] view; returns out (and out2 when the
-    layer is split, i.e. (out, out2))."""
+class Act:
+    """Activation tensor of the LDS-DMA convolution path (csrc/conv_f16x3_dma.hip): "SH32" layout (per pixel and 32
+    channels 32 fp16 hi | 32 fp16 lo, the same 4 bytes per element as fp32) stored inside a buffer with a one-pixel
+    border of zeros, [N, H+2, W+2, C] float32-sized elements, so that 3x3 / pad-1 im2col needs no masks."""
+    __slots__ = ("buf", "n", "h", "w", "c")
+    BORDER = 1
+
+    def __init__(self, buf, n, h, w, c):
+        self.buf, self.n, self.h, self.w, self.c = buf, n, h, w, c
+
+    @property
+    def shape(self):
+        return (self.n, self.h, self.w, self.c)
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def interior_ptr(self):
+        return self.buf.data_ptr() + 4 * ((self.w + 2) * self.c + self.c)
+
+    def strides(self):
+        """(image, row, pixel) strides in floats."""
+        return (self.h + 2) * (self.w + 2) * self.c, (self.w + 2) * self.c, self.c
+
+    def __getitem__(self, sl):
+        """Batch slice (view of the same storage)."""
+        sub = self.buf[sl]
+        return Act(sub, sub.shape[0], self.h, self.w, self.c)
+
+
+_act_scratch = {}
+USE_ACT_PATH = True     # run conv -> conv edges on the LDS-DMA kernels (needs CONV_PRECISION == "f16x3")
+
+
+def act_path():
+    return USE_ACT_PATH and CONV_PRECISION == "f16x3"
+
+
+
+def alloc_act(n, h, w, c, device, tag=None):
+    """Zero-bordered SH32 buffer.  tag=None: fresh storage (for tensors the caller keeps); otherwise a scratch buffer
+    cached per (tag, shape) whose interior the next producer overwrites completely (the border is zeroed once)."""
+    if c % 32:
+        raise MivosHipError(f"SH32 activations need a multiple of 32 channels, got {c}")
+    if tag is None:
+        return Act(torch.zeros((n, h + 2, w + 2, c), dtype=torch.float32, device=device), n, h, w, c)
+    key = (tag, n, h, w, c, device.index, torch.cuda.current_stream().cuda_stream)
+    a = _act_scratch.get(key)
+    if a is None:
+        a = _act_scratch[key] = Act(torch.zeros((n, h + 2, w + 2, c), dtype=torch.float32, device=device), n, h, w, c)
+    return a
+
+
+def to_act(x, relu=False, tag=None, out=None):
+    """fp32 NHWC view -> Act (optionally through ReLU: the DMA-fed kernels cannot apply relu_in)."""
     _ensure_device(x)
+    n, h, w, c = x.shape
+    a = out if out is not None else alloc_act(n, h, w, c, x.device, tag)
+    assert a.shape == (n, h, w, c)
+    if x.stride(3) != 1:
+        x = x.contiguous()
+    sn, sh, sw, _ = x.stride()
+    an, ar, ap = a.strides()
+    check(_lib.load().mivos_pack_activation_sh32(_f32(x).data_ptr(), sn if n > 1 else h * sh, sh, sw, a.interior_ptr(), an, ar, ap,
+                                                 n, h, w, c, int(relu), _stream()))
+    return a
+
+
+def to_f32(a):
+    """Act -> dense fp32 NHWC tensor (x = hi + lo)."""
+    y = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    an, ar, ap = a.strides()
+    n, h, w, c = a.shape
+    check(_lib.load().mivos_unpack_activation_sh32(a.interior_ptr(), an, ar, ap, y.data_ptr(), h * w * c, w * c, c, n, h, w, c, _stream()))
+    return y
+
+
+def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out_act=False, tag=None):
+    """y = act(conv(act_in(x)) * scale + bias + res).  x: fp32 [N,H,W,Cin] view or an Act (then the LDS-DMA kernels run);
+    res: fp32 view or Act; out_act=True returns an Act (only from Act inputs; `out` may be a preallocated Act, `tag` selects
+    a scratch buffer).  Returns out (and out2 when the layer is split, i.e. (out, out2))."""
+    from_act = isinstance(x, Act)
+    if not from_act:
+        _ensure_device(x)
     n, h, w, cin = x.shape
+    dev = x.device
     if cin != L.cin:
         raise MivosHipError(f"conv: input has {cin} channels, layer expects {L.cin}")
+    if from_act and (relu_in or L.cout == 1 or CONV_PRECISION != "f16x3"):
+        raise MivosHipError("conv: an Act input needs the f16x3 back-end, Cout > 1 and relu applied by its producer")
+    if out_act and not from_act:
+        raise MivosHipError("conv: SH32 outputs are written by the LDS-DMA kernels only (Act input)")
     ho = (h + 2 * L.pad - L.k) // L.stride + 1
     wo = (w + 2 * L.pad - L.k) // L.stride + 1
     dual = L.split < L.cout
     if out is None:
-        out = torch.empty((n, ho, wo, L.split), dtype=torch.float32, device=x.device)
+        out = alloc_act(n, ho, wo, L.split, dev, tag) if out_act else torch.empty((n, ho, wo, L.split), dtype=torch.float32, device=dev)
     if dual and out2 is None:
-        out2 = torch.empty((n, ho, wo, L.cout - L.split), dtype=torch.float32, device=x.device)
+        out2 = torch.empty((n, ho, wo, L.cout - L.split), dtype=torch.float32, device=dev)
     d = ConvDesc()
-    if CONV_PRECISION == "f16x3" and L.cout > 1:
+    if from_act:
+        wd, scale16 = L.dma()
+        d.x, d.w, d.scale, d.precision = x.interior_ptr(), wd.data_ptr(), scale16.data_ptr(), 2
+        d.x_nstride, d.x_rstride, d.x_pstride = x.strides()
+        d.x_border, d.x_format = Act.BORDER, 1
+    elif CONV_PRECISION == "f16x3" and L.cout > 1:
         w16, scale16 = L.f16x3()
         d.x, d.w, d.scale, d.precision = _f32(x).data_ptr(), w16.data_ptr(), scale16.data_ptr(), 1
+        d.x_nstride, d.x_pstride = _nhwc_strides(x)
     else:
         d.x, d.w, d.precision = _f32(x).data_ptr(), L.w.data_ptr(), 0
         d.scale = L.scale.data_ptr() if L.scale is not None else None
+        d.x_nstride, d.x_pstride = _nhwc_strides(x)
     d.bias = L.bias.data_ptr() if L.bias is not None else None
-    d.y = out.data_ptr()
     d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = n, h, w, cin, L.cout, L.k, L.k
     d.stride, d.pad, d.Ho, d.Wo, d.split = L.stride, L.pad, ho, wo, L.split
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)
-    d.x_nstride, d.x_pstride = _nhwc_strides(x)
-    assert out.shape == (n, ho, wo, L.split), (out.shape, (n, ho, wo, L.split))
-    d.y_nstride, d.y_pstride = _nhwc_strides(out)
+    assert tuple(out.shape) == (n, ho, wo, L.split), (out.shape, (n, ho, wo, L.split))
+    if isinstance(out, Act):
+        d.y, d.y_format = out.interior_ptr(), 1
+        d.y_nstride, d.y_rstride, d.y_pstride = out.strides()
+    else:
+        d.y = out.data_ptr()
+        d.y_nstride, d.y_pstride = _nhwc_strides(out)
     if dual:
         assert out2.shape == (n, ho, wo, L.cout - L.split)
         d.y2 = out2.data_ptr()
         d.y2_nstride, d.y2_pstride = _nhwc_strides(out2)
     if res is not None:
-        assert res.shape[1:] == (ho, wo, L.cout) and res.shape[0] in (1, n)
-        d.res = _f32(res).data_ptr()
-        rn, rp = _nhwc_strides(res)
+        assert tuple(res.shape[1:]) == (ho, wo, L.cout) and res.shape[0] in (1, n)
+        if isinstance(res, Act):
+            d.res, d.res_format = res.interior_ptr(), 1
+            rn, d.res_rstride, rp = res.strides()
+        else:
+            d.res = _f32(res).data_ptr()
+            rn, rp = _nhwc_strides(res)
         d.res_nstride, d.res_pstride = (0 if (res.shape[0] == 1 and n > 1) else rn), rp
-    ws = _workspace(SPLITK_WORKSPACE_BYTES, x.device)
+    ws = _workspace(SPLITK_WORKSPACE_BYTES, dev)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -163,10 +281,16 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None):
     if PROFILE is not None:
         ev1.record()
         m = n * ho * wo
-        var = _lib.load().mivos_conv2d_variant_f16x3(m, L.cout) + 10 if d.precision == 1 else _lib.load().mivos_conv2d_variant(m, L.cout)
-        if d.precision == 1 and L.cout == 32 and L.k == 3 and L.stride == 1 and cin in (16, 32):
-            var = 19
-        PROFILE.append((var, 2.0 * m * L.cout * L.k * L.k * cin, ev0, ev1, (m, cin, L.cout, L.k, L.stride)))
+        lib = _lib.load()
+        if d.precision == 2:
+            var = lib.mivos_conv2d_variant_pp(m, L.cout)
+        elif d.precision == 1:
+            var = lib.mivos_conv2d_variant_f16x3(m, L.cout) + 10
+            if L.cout == 32 and L.k == 3 and L.stride == 1 and cin in (16, 32):
+                var = 19
+        else:
+            var = lib.mivos_conv2d_variant(m, L.cout)
+        PROFILE.append((var, 2.0 * m * L.cout * L.k * L.k * cin, ev0, ev1, (m, cin, L.cout, L.k, L.stride, res is not None)))
     return (out, out2) if dual else out
 
 
