@@ -124,8 +124,9 @@ int mivos_conv2d_variant(int M, int Cout);
 /* Same for precision 1 (f16x3): additionally 5: 256x256 tile / 8 waves pipelined, 6: 128x256 / 8 waves,
  * 7: 128x128 / 8 waves. */
 int mivos_conv2d_variant_f16x3(int M, int Cout);
-/* Same for precision 2 (LDS-DMA ping-pong kernels): 20: 128x128 tile, 21: 128x256, 22: 128x64, 23: 256x256. */
-int mivos_conv2d_variant_pp(int M, int Cout);
+/* Same for precision 2 (LDS-DMA ping-pong kernels): 20: 128x128 tile, 21: 128x256, 22: 128x64, 23: 256x256;
+ * ksteps = KH*KW*Cin/32. */
+int mivos_conv2d_variant_pp(int M, int Cout, int ksteps);
 
 /* MaxPool2d(3, stride 2, pad 1) on NHWC (mod_resnet.py:121 / torchvision stem). C % 4 == 0. */
 int mivos_maxpool3x3s2(const float *x, float *y, int N, int H, int W, int C, void *stream);

@@ -44,7 +44,7 @@ PROTOTYPES = {
     "mivos_pack_weights_f16x3_dma": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "mivos_conv2d_variant": (C.c_int, [C.c_int, C.c_int]),
     "mivos_conv2d_variant_f16x3": (C.c_int, [C.c_int, C.c_int]),
-    "mivos_conv2d_variant_pp": (C.c_int, [C.c_int, C.c_int]),
+    "mivos_conv2d_variant_pp": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "mivos_maxpool3x3s2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_upsample2x_add": (C.c_int, [vp, i64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_memory_read_workspace_bytes": (i64, [C.c_int, i64, C.c_int, C.c_int]),

@@ -137,6 +137,68 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float 
   }
 }
 
+// SH32-output epilogue (y_fmt == 1, single destination): a lane owns 8 consecutive channels of one pixel, so the fp16 hi
+// and lo parts go out as one 16-byte store each (4 lanes cover the 64 B hi + 64 B lo halves of a 128-byte line) and an
+// SH32 residual comes in as two 16-byte loads.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue_sh32(const f32x16 (&acc)[MT][NT], float *scratch, const ConvP &p, int m_base, int n_base, int lane) {
+  const int prow0 = lane >> 2, c8 = (lane & 3) * 8;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n_base + j * 32 + c8;
+    const bool nok = n < p.Cout;
+    float sc[8], bi[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { sc[q] = 1.f; bi[q] = 0.f; }
+    if (nok && p.scale) { const f32x4 a = *reinterpret_cast<const f32x4 *>(p.scale + n), b = *reinterpret_cast<const f32x4 *>(p.scale + n + 4);
+      sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w; }
+    if (nok && p.bias) { const f32x4 a = *reinterpret_cast<const f32x4 *>(p.bias + n), b = *reinterpret_cast<const f32x4 *>(p.bias + n + 4);
+      bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scratch[mfma32_row(r, lane) * EPI_PITCH + (lane & 31)] = acc[i][j][r];
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int prow = ps * 16 + prow0;
+        const int m = m_base + i * 32 + prow;
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(scratch + prow * EPI_PITCH + c8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(scratch + prow * EPI_PITCH + c8 + 4);
+        if (m < p.M && nok) {
+          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          const int img = m / p.HoWo, pix = m - img * p.HoWo;
+          const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = v[q] * sc[q] + bi[q];
+          if (p.res) {
+            const long long ro = (long long)img * p.r_ns + (long long)oh * p.r_rs + (long long)ow * p.r_ps;
+            if (p.r_fmt) {
+              const unsigned char *rq = reinterpret_cast<const unsigned char *>(p.res + ro) + (n >> 5) * 128 + (n & 31) * 2;
+              const half8_t rh = *reinterpret_cast<const half8_t *>(rq), rl = *reinterpret_cast<const half8_t *>(rq + 64);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] += (float)rh[q] + (float)rl[q];
+            } else {
+              const f32x4 a = *reinterpret_cast<const f32x4 *>(p.res + ro + n), b = *reinterpret_cast<const f32x4 *>(p.res + ro + n + 4);
+              v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+            }
+          }
+          half8_t hi, lo;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float t = p.relu_out ? fmaxf(v[q], 0.f) : v[q];
+            hi[q] = (_Float16)t;
+            lo[q] = (_Float16)(t - (float)hi[q]);
+          }
+          unsigned char *yq = reinterpret_cast<unsigned char *>(p.y + (long long)img * p.y_ns + (long long)oh * p.y_rs + (long long)ow * p.y_ps) + (n >> 5) * 128 + (n & 31) * 2;
+          *reinterpret_cast<half8_t *>(yq) = hi;
+          *reinterpret_cast<half8_t *>(yq + 64) = lo;
+        }
+      }
+    }
+  }
+}
+
 // fills ConvP from the public descriptor after validating it; returns a status code
 int conv_params_from_desc(const mivos_conv_desc *d, ConvP &p);
 int launch_conv_f16x3(ConvP &p, hipStream_t st);

@@ -238,7 +238,8 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
     epilogue_vec<MT, NT>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, q, m0 + wm * TM, n0 + wn * TN, lane);
     return;
   }
-  if (p.vec_epi) epilogue_vec<MT, NT>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
+  if (p.y_fmt && p.split == p.Cout) epilogue_sh32<MT, NT>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
+  else if (p.vec_epi) epilogue_vec<MT, NT>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
   else epilogue_scalar<MT, NT>(acc, p, m0 + wm * TM, n0 + wn * TN, lane);
 #endif
 }
@@ -346,12 +347,12 @@ static int launch_pp(ConvP &p, hipStream_t st) {
   return check_launch("conv_f16x3_pp");
 }
 
-// Tile selection for precision 2.  20: 128x128 (80 KB LDS: two workgroups per CU overlap each other's barrier
+// Tile selection for precision 2 (nk = K steps of 32 channels x 1 tap).  20: 128x128 (80 KB LDS: two workgroups per CU overlap each other's barrier
 // bubbles; the robust default), 21: 128x256 (one workgroup per CU; wins when its tiles fill whole rounds of the
 // 256 CUs), 22: 128x64 (Cout <= 64), 23: 256x256 (profiling only: equal to 20 on its best shapes).
-int select_variant_pp(int M, int Cout) {
+int select_variant_pp(int M, int Cout, int nk) {
   if (Cout <= 64) return 22;
-  if (Cout % 256 == 0) {
+  if (Cout % 256 == 0 && nk >= 36) {      // short-K (1x1) layers are bound by loads/stores: two workgroups per CU overlap them
     const long long t = (long long)cdiv(M, 128) * (Cout / 256);
     const long long rounds = (t + 255) / 256;
     if (t >= 200 && (double)t / (double)(rounds * 256) >= 0.85) return 21;
@@ -365,7 +366,7 @@ int launch_conv_f16x3_dma(ConvP &p, hipStream_t st) {
   if ((p.x_ps & 31) || (p.x_ns & 31) || (p.x_rs & 31)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d (SH32 input): strides must be multiples of 32");
   if (p.x_border < p.pad) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d (SH32 input): needs a zero border >= pad around every image");
   static const int force = getenv("MIVOS_PP_TILE") ? atoi(getenv("MIVOS_PP_TILE")) : 0;   // tuning only
-  switch (force ? force : select_variant_pp(p.M, p.Cout)) {
+  switch (force ? force : select_variant_pp(p.M, p.Cout, (p.Cin >> 5) * p.KH * p.KW)) {
     case 23: {
       static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;   // profiling only
       if (abl == 1) return launch_pp<256, 256, 2, 4, 1>(p, st);
@@ -383,7 +384,7 @@ int launch_conv_f16x3_dma(ConvP &p, hipStream_t st) {
 
 using namespace mivos;
 
-extern "C" int mivos_conv2d_variant_pp(int M, int Cout) { return select_variant_pp(M, Cout); }
+extern "C" int mivos_conv2d_variant_pp(int M, int Cout, int ksteps) { return select_variant_pp(M, Cout, ksteps); }
 
 extern "C" int mivos_pack_activation_sh32(const float *x, int64_t x_nstride, int64_t x_rstride, int64_t x_pstride, void *y, int64_t y_nstride,
                                            int64_t y_rstride, int64_t y_pstride, int N, int H, int W, int C, int relu, void *stream) {

@@ -238,10 +238,10 @@ int conv_params_from_desc(const mivos_conv_desc *d, ConvP &p) {
   if (d->precision != 2 && p.x_rs != (long long)d->W * d->x_pstride) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: precision 0/1 read dense input rows");
   if (d->precision != 2 && (p.y_rs != (long long)d->Wo * d->y_pstride || (d->res && p.r_rs != (long long)d->Wo * d->res_pstride)))
     return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: precision 0/1 write / add dense rows");
-  if ((p.y_rs | p.r_rs | p.x_rs) & 3) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: row strides %% 4 != 0");
+  if (p.x_rs & 3) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: x row stride %% 4 != 0");
   auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
-  p.vec_epi = !(p.Cout & 3) && !(p.split & 3) && !((p.y_ns | p.y_ps) & 3) && al16(p.y) && al16(p.scale) && al16(p.bias) &&
-              (!dual || (!((p.y2_ns | p.y2_ps) & 3) && al16(p.y2))) && (!p.res || (!((p.r_ns | p.r_ps) & 3) && al16(p.res)));
+  p.vec_epi = !(p.Cout & 3) && !(p.split & 3) && !((p.y_ns | p.y_ps | p.y_rs) & 3) && al16(p.y) && al16(p.scale) && al16(p.bias) &&
+              (!dual || (!((p.y2_ns | p.y2_ps) & 3) && al16(p.y2))) && (!p.res || (!((p.r_ns | p.r_ps | p.r_rs) & 3) && al16(p.res)));
   if ((p.y_fmt || p.r_fmt) && (!p.vec_epi || (p.split & 31) || ((p.y_ps | p.y_rs | p.y_ns) & 31 && p.y_fmt) || (p.r_fmt && ((p.r_ps | p.r_rs | p.r_ns) & 31))))
     return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: SH32 output / residual needs 32-channel groups, strides %% 32 == 0 and 16-byte aligned operands");
   if ((p.y_fmt || p.r_fmt) && d->precision != 2) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: SH32 output / residual is implemented by the precision-2 kernels only");

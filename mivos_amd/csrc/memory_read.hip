@@ -341,11 +341,13 @@ struct SplitPlan { int n_split; long long chunk; };
 static SplitPlan plan_split(int n_obj, long long n_mem, int n_q) {
   const long long q_tiles = cdiv(n_q, QT), tiles = cdiv(n_mem, KT);
   // Selection work grows with the number of chunks (every chunk keeps its own top-k: k(1 + ln(n/k)) appends),
-  // MFMA work does not.  Short memories (480p, T <= ~30): one round of <= 256 workgroups.  Long memories
+  // MFMA work does not.  Short memories (480p, T <= ~30): one round of <= 512 workgroups
+  // (two per CU: measured 1.2x over one per CU at K=5, T=12).  Long memories
   // (>= 512 tiles per chunk, where selection is negligible): up to 3 workgroups per CU so that barriers and
   // compactions of one workgroup hide behind the MFMAs of the others.
   const long long wg = q_tiles * n_obj;
-  long long s = 256 / wg;
+  static const int target = getenv("MIVOS_MEMREAD_WGS") ? atoi(getenv("MIVOS_MEMREAD_WGS")) : 512;   // tuning only (two 4-wave workgroups per CU)
+  long long s = target / wg;
   if (s < 1) s = 1;
   const long long s3 = cdiv(768, wg), by_len = tiles / 512;
   if (by_len > s) s = by_len < s3 ? by_len : s3;

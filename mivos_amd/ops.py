@@ -283,7 +283,7 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
         m = n * ho * wo
         lib = _lib.load()
         if d.precision == 2:
-            var = lib.mivos_conv2d_variant_pp(m, L.cout)
+            var = lib.mivos_conv2d_variant_pp(m, L.cout, L.k * L.k * cin // 32)
         elif d.precision == 1:
             var = lib.mivos_conv2d_variant_f16x3(m, L.cout) + 10
             if L.cout == 32 and L.k == 3 and L.stride == 1 and cin in (16, 32):

@@ -78,12 +78,20 @@ for name, n, h, w, cin, cout, k, s in SHAPES:
     d.x_nstride, d.x_rstride, d.x_pstride, d.x_border, d.x_format = ns, rs, cin, 1, 1
     d.y_nstride, d.y_pstride = y1.shape[1] * y1.shape[2] * cout, cout
     d.res_nstride, d.res_pstride = d.y_nstride, cout
+    sh_io = bool(os.environ.get("SH"))          # SH=1: SH32 output and SH32 residual as in the engine
+    if sh_io:
+        res_a, out_a = ops.to_act(res), ops.alloc_act(*y1.shape, x.device)
+        d.res, d.res_format, d.y, d.y_format = res_a.interior_ptr(), 1, out_a.interior_ptr(), 1
+        d.res_nstride, d.res_rstride, d.res_pstride = res_a.strides()
+        d.y_nstride, d.y_rstride, d.y_pstride = out_a.strides()
     ws = ops._workspace(ops.SPLITK_WORKSPACE_BYTES, x.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     run = lambda: check(lib.mivos_conv2d_fused(C.byref(d), st()))
     t2 = timeit(run)
     m = y1.shape[0] * y1.shape[1] * y1.shape[2]
     fl = 2.0 * m * cout * k * k * cin
+    if sh_io:
+        y2 = ops.to_f32(out_a)
     diff = float((y1 - y2).abs().max())
-    print(f"{name:30s} M={m:7d} var {lib.mivos_conv2d_variant_f16x3(m, cout)}/{lib.mivos_conv2d_variant_pp(m, cout)}  reg {t1*1e3:8.1f} us {fl/t1/1e9:6.1f} TF/s | "
+    print(f"{name:30s} M={m:7d} var {lib.mivos_conv2d_variant_f16x3(m, cout)}/{lib.mivos_conv2d_variant_pp(m, cout, k * k * cin // 32)}  reg {t1*1e3:8.1f} us {fl/t1/1e9:6.1f} TF/s | "
           f"dma {t2*1e3:8.1f} us {fl/t2/1e9:6.1f} TF/s  x{t1/t2:4.2f}  max|diff| {diff:.3g} (|y| max {float(y1.abs().max()):.3g})")
