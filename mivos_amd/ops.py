@@ -197,9 +197,11 @@ def to_act(x, relu=False, tag=None, out=None):
     if x.stride(3) != 1:
         x = x.contiguous()
     sn, sh, sw, _ = x.stride()
+    sw = sw if w > 1 else c                 # strides of size-1 dimensions are arbitrary in torch: use the dense ones
+    sh = sh if h > 1 else w * sw
+    sn = sn if n > 1 else h * sh
     an, ar, ap = a.strides()
-    check(_lib.load().mivos_pack_activation_sh32(_f32(x).data_ptr(), sn if n > 1 else h * sh, sh, sw, a.interior_ptr(), an, ar, ap,
-                                                 n, h, w, c, int(relu), _stream()))
+    check(_lib.load().mivos_pack_activation_sh32(_f32(x).data_ptr(), sn, sh, sw, a.interior_ptr(), an, ar, ap, n, h, w, c, int(relu), _stream()))
     return a
 
 

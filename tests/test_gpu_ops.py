@@ -124,6 +124,110 @@ def test_conv3x3_direct_patch_kernel_ragged(shape, monkeypatch):
     assert rel_err(got, ref) < 2e-6
 
 
+DMA_CASES = [
+    # n, cin, cout, k, stride, pad, h, w, relu_out, res ("", "f32", "act"), bn, out_act
+    (1, 64, 64, 1, 1, 0, 30, 54, True, "", True, True),          # 128x64 tile
+    (2, 64, 256, 1, 1, 0, 17, 23, True, "act", True, True),      # ragged M, SH32 residual, SH32 out (bottleneck conv3)
+    (1, 256, 128, 1, 2, 0, 30, 54, False, "", True, True),       # strided 1x1 (downsample)
+    (1, 128, 128, 3, 2, 1, 31, 37, True, "", True, True),        # 3x3 stride 2, odd size: border taps on every side
+    (3, 64, 96, 3, 1, 1, 20, 28, False, "f32", False, False),    # Cout not a multiple of the tile, fp32 residual + output
+    (1, 1024, 640, 3, 1, 1, 8, 10, False, "", False, False),     # KeyValue-like: K = 288 steps, split-K over the workspace
+    (5, 256, 256, 3, 1, 1, 120, 216, False, "f32", False, False),  # largest decoder shape (128x256 tiles)
+    (1, 512, 200, 3, 1, 1, 9, 11, True, "f32", False, True),     # Cout % 32 != 0: SH32 output refused, columns past Cout masked, split-K
+    (1, 512, 192, 3, 1, 1, 9, 11, True, "act", False, True),     # split-K reduce with SH32 residual and SH32 output
+    (2, 32, 160, 1, 1, 0, 5, 7, False, "", False, True),         # a single K step (prologue-only pipeline)
+    (1, 64, 128, 3, 1, 1, 1, 1, False, "", False, True),         # 1x1 image: every tap but the centre reads the border
+]
+
+
+@pytest.mark.parametrize("case", DMA_CASES, ids=lambda c: "x".join(map(str, c[:8])))
+def test_conv2d_lds_dma_path(case):
+    """Precision 2 (conv_f16x3_dma.hip): SH32 activations in zero-bordered buffers in, SH32 or fp32 out, against fp64."""
+    n, cin, cout, k, stride, pad, h, w, relu_out, res_kind, use_bn, out_act = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    bn = None
+    if use_bn:
+        bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
+              torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=pad)
+    if bn is not None:
+        ref = F.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0., 1e-5)
+    res = None
+    if res_kind:
+        res = torch.randn(n, cout, ref.shape[2], ref.shape[3], generator=g)
+        ref = ref + res.double()
+    if relu_out:
+        ref = F.relu(ref)
+    L = ConvLayer.pack(wt, b, bn, stride, pad).to(DEV)
+    xa = ops.to_act(nhwc(x).to(DEV))
+    assert float((ops.to_f32(xa).cpu() - nhwc(x)).abs().max()) <= 2.0 ** -21 * float(x.abs().max())      # hi + lo keeps 22 bits
+    r = None
+    if res_kind == "f32":
+        r = nhwc(res).to(DEV)
+    elif res_kind == "act":
+        r = ops.to_act(nhwc(res).to(DEV))
+    if out_act and cout % 32:
+        with pytest.raises(ops.MivosHipError):
+            ops.conv(xa, L, relu_out=relu_out, res=r, out_act=True)
+        out_act = False
+    got = ops.conv(xa, L, relu_out=relu_out, res=r, out_act=out_act)
+    if out_act:
+        border = got.buf.clone()
+        border[:, 1:-1, 1:-1] = 0
+        assert float(border.abs().max()) == 0                      # the zero border survives the epilogue
+        got = ops.to_f32(got)
+    torch.cuda.synchronize()
+    err = rel_err(got.cpu().permute(0, 3, 1, 2), ref)
+    print(f"lds-dma: rel err vs fp64 {err:.2e}")
+    assert err < max(2e-6, 6e-8 * (cin * k * k) ** 0.5)
+
+
+def test_conv2d_lds_dma_matches_register_staged_kernel_bitwise():
+    """Same products, same accumulation order: the two f16x3 back-ends agree bit for bit (no split-K on either side)."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(5, 60, 108, 128, generator=g).to(DEV)         # 254 tiles of 128x128: neither back-end splits K
+    L = ConvLayer.pack(torch.randn(128, 128, 3, 3, generator=g) * 0.03, torch.randn(128, generator=g) * 0.1, None, 1, 1).to(DEV)
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f16x3"
+    try:
+        a = ops.conv(x, L, relu_out=True)
+        b = ops.conv(ops.to_act(x), L, relu_out=True)
+    finally:
+        ops.CONV_PRECISION = old
+    # x itself is rounded to hi + lo by to_act exactly as the register-staged kernel does while staging
+    assert torch.equal(a, b)
+
+
+def test_conv2d_lds_dma_dual_destination_and_batch_slices():
+    """KeyValue-style split into two fp32 destinations from an Act input; Act batch slices keep their borders."""
+    g = torch.Generator().manual_seed(3)
+    n, h, w = 3, 9, 12
+    x = torch.randn(n, h, w, 64, generator=g).to(DEV)
+    wt, b = torch.randn(96, 64, 3, 3, generator=g) * 0.05, torch.randn(96, generator=g) * 0.1
+    L = ConvLayer.pack(wt, b, None, 1, 1)
+    L.split = 32
+    L = L.to(DEV)
+    xa = ops.to_act(x)
+    y1, y2 = ops.conv(xa, L)
+    ref = F.conv2d(x.cpu().permute(0, 3, 1, 2).double(), wt.double(), b.double(), padding=1)
+    assert rel_err(torch.cat([y1, y2], -1).cpu().permute(0, 3, 1, 2), ref) < 2e-6
+    z1, z2 = ops.conv(xa[1:2], L)
+    assert torch.equal(z1, y1[1:2]) and torch.equal(z2, y2[1:2])
+
+
+def test_conv2d_lds_dma_rejects_what_it_cannot_do():
+    L = ConvLayer.pack(torch.randn(64, 64, 3, 3), None, None, 1, 1).to(DEV)
+    xa = ops.to_act(torch.randn(1, 8, 8, 64, device=DEV))
+    with pytest.raises(ops.MivosHipError):
+        ops.conv(xa, L, relu_in=True)                                       # a DMA-staged operand cannot be modified on load
+    with pytest.raises(ops.MivosHipError):
+        ops.conv(torch.randn(1, 8, 8, 64, device=DEV), L, out_act=True)     # SH32 outputs come from the LDS-DMA kernels only
+    with pytest.raises(ops.MivosHipError):
+        ops.alloc_act(1, 8, 8, 48, torch.device(DEV))                       # channels % 32
+
+
 def test_conv_rejects_bad_arguments():
     L = ConvLayer.pack(torch.randn(8, 12, 3, 3), None, None, 1, 1).to(DEV)
     with pytest.raises(ops.MivosHipError):
