@@ -334,12 +334,15 @@ static int launch_pp(ConvP &p, hipStream_t st) {
   // split-K when the tile grid cannot fill the chip and K is long (30x54 layers at small batch)
   const int nk = (p.Cin >> 5) * p.KH * p.KW, wgs = tiles_m * p.tiles_n, cap = lds <= 80 * 1024 ? 512 : 256;
   int slices = 1;
-  if (p.vec_epi && p.ws && wgs * 3 <= cap && nk >= 16) {
-    slices = cap / wgs;
+  static const int thr6 = getenv("MIVOS_PP_SPLIT_THR") ? atoi(getenv("MIVOS_PP_SPLIT_THR")) : 4;   // tuning only: split when fewer than thr6/6 of the workgroup slots are filled (A/B: +0.7 % end to end vs 2)
+  if (p.vec_epi && p.ws && wgs * 6 <= cap * thr6 && nk >= 16) {
+    slices = cap / wgs < 2 ? 2 : cap / wgs;
     if (slices > 8) slices = 8;
     if (slices > nk / 8) slices = nk / 8;
     if ((long long)slices * p.M * p.Cout * 4 > p.ws_bytes) slices = 1;
   }
+  static const int force_slices = getenv("MIVOS_PP_SPLIT") ? atoi(getenv("MIVOS_PP_SPLIT")) : 0;   // tuning only
+  if (force_slices && p.vec_epi && p.ws && (long long)force_slices * p.M * p.Cout * 4 <= p.ws_bytes && nk >= 2 * force_slices) slices = force_slices;
   p.kt_split = 0;
   if (slices > 1) { p.kt_split = cdiv(nk, slices); slices = cdiv(nk, p.kt_split); p.partial = (float *)p.ws; }
   hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n, slices), dim3(512), lds, st, p, (unsigned)x_bytes, (unsigned)w_bytes);
