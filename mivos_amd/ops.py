@@ -184,6 +184,8 @@ def alloc_act(n, h, w, c, device, tag=None):
     key = (tag, n, h, w, c, device.index, torch.cuda.current_stream().cuda_stream)
     a = _act_scratch.get(key)
     if a is None:
+        if len(_act_scratch) >= 256:      # many different clip sizes in one process: start over instead of growing forever
+            _act_scratch.clear()
         a = _act_scratch[key] = Act(torch.zeros((n, h + 2, w + 2, c), dtype=torch.float32, device=device), n, h, w, c)
     return a
 
