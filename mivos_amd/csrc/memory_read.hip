@@ -78,21 +78,28 @@ __device__ __forceinline__ void compact_query(uint64_t *buf, int *cnt, float *ta
     a[t] = (uint32_t)(e[t] >> 32);                        // 0 = empty (below every valid score)
   }
   if (n <= k) return;                                     // nothing to drop, threshold unchanged
+  // k-th largest orderable score = the largest v with #(a >= v) >= k: bisect its 32 bits MSB-first, ONE vector compare
+  // per entry and bit (the counts come from scalar popcounts of the ballots: this code runs beside other waves' MFMA
+  // streams, where every vector-ALU instruction costs a whole MFMA slot)
   uint32_t prefix = 0;
-  int rem = k;
 #pragma unroll 1
   for (int b = 31; b >= 0; --b) {
-    const uint32_t cand = prefix | (1u << b), msk = ~((1u << b) - 1u);
+    const uint32_t trial = prefix | (1u << b);
     int c = 0;
 #pragma unroll
-    for (int t = 0; t < EPL; ++t) c += __popcll(__ballot((a[t] & msk) == cand));
-    if (c >= rem) prefix = cand; else rem -= c;
+    for (int t = 0; t < EPL; ++t) c += __popcll(__ballot(a[t] >= trial));
+    if (c >= k) prefix = trial;
   }
   // prefix = k-th largest score; rem = how many entries equal to it must be kept
   bool eq[EPL];
-  int neq = 0;
+  int neq = 0, ngt = 0;
 #pragma unroll
-  for (int t = 0; t < EPL; ++t) { eq[t] = a[t] == prefix; neq += __popcll(__ballot(eq[t])); }
+  for (int t = 0; t < EPL; ++t) {
+    eq[t] = a[t] == prefix;
+    neq += __popcll(__ballot(eq[t]));
+    ngt += __popcll(__ballot(a[t] > prefix));
+  }
+  const int rem = k - ngt;
   if (neq != rem) {                                        // rare: exact ties straddle the cut -> lowest indices win
     int r[EPL];
 #pragma unroll
@@ -218,21 +225,29 @@ __global__ __launch_bounds__(256) void memread_select_kernel(const float *__rest
         }
         my_tau = tau[qslot];
       }
-      // one LDS atomic per lane and half-tile: reserve as many slots as this lane has passing scores
+      // one LDS atomic per lane and half-tile: reserve as many slots as this lane has passing scores.
+      // (selection VALU is the bound here - one VALU issue per MFMA of the co-resident waves - so: 32-bit row
+      // arithmetic, and the row-in-range test only on the last, partial tile of a chunk)
       uint32_t passmask = 0;
+      const int rows_left = (int)(c1 - kb);                  // >= KT on every tile but the last
+      if (rows_left >= KT) {
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        const int r = half * 8 + rr;
-        const long long m = kb + mfma32_row(r, lane);
-        passmask |= (uint32_t)(m < c1 && acc[r] > my_tau) << rr;
+        for (int rr = 0; rr < 8; ++rr) passmask |= (uint32_t)(acc[half * 8 + rr] > my_tau) << rr;
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int r = half * 8 + rr;
+          passmask |= (uint32_t)(mfma32_row(r, lane) < rows_left && acc[r] > my_tau) << rr;
+        }
       }
       if (passmask) {
+        const uint32_t kb32 = (uint32_t)kb;
         int pos = atomicAdd(cnt + qslot, __popc(passmask));
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
           if (passmask & (1u << rr)) {
             const int r = half * 8 + rr;
-            cand[qslot * CAP + pos++] = pack_cand(acc[r], (uint32_t)(kb + mfma32_row(r, lane)));
+            cand[qslot * CAP + pos++] = pack_cand(acc[r], kb32 + (uint32_t)mfma32_row(r, lane));
           }
         }
       }

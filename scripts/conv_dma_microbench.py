@@ -25,6 +25,7 @@ SHAPES = [  # name, N, H, W, Cin, Cout, k, stride
     ("enc.l3 1x1 256->1024 b5", 5, 30, 54, 256, 1024, 1, 1),
     ("enc.l3 1x1 1024->256 b5", 5, 30, 54, 1024, 256, 1, 1),
     ("ragged 3x3 64->96", 2, 37, 53, 64, 96, 3, 1),
+    ("fusion 3x3 32->32 b5", 5, 480, 864, 32, 32, 3, 1),
     ("kv 3x3 1024->640 b5", 5, 30, 54, 1024, 640, 3, 1),
     ("kv 3x3 1024->640 b1", 1, 30, 54, 1024, 640, 3, 1),
     ("enc.l3 3x3 256->256 b1", 1, 30, 54, 256, 256, 3, 1),
