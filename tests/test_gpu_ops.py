@@ -188,7 +188,7 @@ def test_conv2d_lds_dma_path(case):
 def test_conv2d_lds_dma_matches_register_staged_kernel_bitwise():
     """Same products, same accumulation order: the two f16x3 back-ends agree bit for bit (no split-K on either side)."""
     g = torch.Generator().manual_seed(77)
-    x = torch.randn(5, 60, 108, 128, generator=g).to(DEV)         # 254 tiles of 128x128: neither back-end splits K
+    x = torch.randn(8, 60, 108, 128, generator=g).to(DEV)         # 405 tiles of 128x128: neither back-end splits K
     L = ConvLayer.pack(torch.randn(128, 128, 3, 3, generator=g) * 0.03, torch.randn(128, generator=g) * 0.1, None, 1, 1).to(DEV)
     old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f16x3"
     try:
