@@ -93,9 +93,10 @@ __device__ __forceinline__ void epilogue_scalar(const f32x16 (&acc)[MT][NT], con
 // accesses, 8 lanes per 128-B line (the memory-bound 1x1 expansion convs were store-issue bound with one
 // dword per lane: 1.5 TB/s).  Needs Cout, split and all strides % 4 == 0 (p.vec_epi, checked on the host).
 constexpr int EPI_PITCH = 36;
-template <int MT, int NT>
+template <int MT, int NT, int IB = (MT > 2 ? 1 : MT)>   // IB: row tiles per residual-prefetch block (bounds the live registers)
 __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float *scratch, const ConvP &p, int m_base,
                                              int n_base, int lane) {
+  constexpr bool PREFETCH = MT <= 2;       // 256x256 tiles (128 accumulator VGPRs) have no registers to spare for it
   const int prow0 = lane >> 3, c4 = (lane & 7) * 4;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -110,27 +111,49 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float 
     if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_rs = p.y_rs; d_ps = p.y_ps; dn = n; d_fmt = p.y_fmt; }
     else { dst = p.y2; d_ns = p.y2_ns; d_rs = p.y2_rs; d_ps = p.y2_ps; dn = n - p.split; d_fmt = 0; }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int i0 = 0; i0 < MT; i0 += IB) {
+      // output offsets + ALL residual loads of IB row tiles in flight before the first one is needed: one memory latency
+      // per block instead of one per 8 pixel rows (with one workgroup per CU nothing else hides them)
+      long long yo[IB][4];
+      f32x4 rr[IB][4];
+      bool ok[IB][4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) scratch[mfma32_row(r, lane) * EPI_PITCH + (lane & 31)] = acc[i][j][r];
+      for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        const int prow = ps * 8 + prow0;
-        const int m = m_base + i * 32 + prow;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(scratch + prow * EPI_PITCH + c4);
-        if (m < p.M && nok) {
-          const int img = m / p.HoWo, pix = m - img * p.HoWo;
+        for (int ps = 0; ps < 4; ++ps) {
+          const int m = m_base + (i0 + ii) * 32 + ps * 8 + prow0;
+          ok[ii][ps] = m < p.M && nok;
+          const int mm = m < p.M ? m : 0;
+          const int img = mm / p.HoWo, pix = mm - img * p.HoWo;
           const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
-          v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
-          if (p.res) {
+          yo[ii][ps] = (long long)img * d_ns + (long long)oh * d_rs + (long long)ow * d_ps;
+          rr[ii][ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (PREFETCH && p.res && ok[ii][ps]) {
             const long long ro = (long long)img * p.r_ns + (long long)oh * p.r_rs + (long long)ow * p.r_ps;
-            const f32x4 rr = p.r_fmt ? load_sh32x4(p.res, ro, n) : *reinterpret_cast<const f32x4 *>(p.res + ro + n);
-            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            rr[ii][ps] = p.r_fmt ? load_sh32x4(p.res, ro, n) : *reinterpret_cast<const f32x4 *>(p.res + ro + n);
           }
-          if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          const long long yo = (long long)img * d_ns + (long long)oh * d_rs + (long long)ow * d_ps;
-          if (d_fmt) store_sh32x4(dst, yo, dn, v);
-          else *reinterpret_cast<f32x4 *>(dst + yo + dn) = v;
+        }
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scratch[mfma32_row(r, lane) * EPI_PITCH + (lane & 31)] = acc[i0 + ii][j][r];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          f32x4 v = *reinterpret_cast<const f32x4 *>(scratch + (ps * 8 + prow0) * EPI_PITCH + c4);
+          if (ok[ii][ps]) {
+            v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
+            if (!PREFETCH && p.res) {
+              const int m = m_base + (i0 + ii) * 32 + ps * 8 + prow0;
+              const int img = m / p.HoWo, pix = m - img * p.HoWo;
+              const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
+              const long long ro = (long long)img * p.r_ns + (long long)oh * p.r_rs + (long long)ow * p.r_ps;
+              rr[ii][ps] = p.r_fmt ? load_sh32x4(p.res, ro, n) : *reinterpret_cast<const f32x4 *>(p.res + ro + n);
+            }
+            v.x += rr[ii][ps].x; v.y += rr[ii][ps].y; v.z += rr[ii][ps].z; v.w += rr[ii][ps].w;
+            if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (d_fmt) store_sh32x4(dst, yo[ii][ps], dn, v);
+            else *reinterpret_cast<f32x4 *>(dst + yo[ii][ps] + dn) = v;
+          }
         }
       }
     }
@@ -141,8 +164,9 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float 
 // and lo parts go out as one 16-byte store each (4 lanes cover the 64 B hi + 64 B lo halves of a 128-byte line) and an
 // SH32 residual comes in as two 16-byte loads.
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-template <int MT, int NT>
+template <int MT, int NT, int IB = (MT > 2 ? 1 : MT)>
 __device__ __forceinline__ void epilogue_sh32(const f32x16 (&acc)[MT][NT], float *scratch, const ConvP &p, int m_base, int n_base, int lane) {
+  constexpr bool PREFETCH = MT <= 2;
   const int prow0 = lane >> 2, c8 = (lane & 3) * 8;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -156,43 +180,61 @@ __device__ __forceinline__ void epilogue_sh32(const f32x16 (&acc)[MT][NT], float
     if (nok && p.bias) { const f32x4 a = *reinterpret_cast<const f32x4 *>(p.bias + n), b = *reinterpret_cast<const f32x4 *>(p.bias + n + 4);
       bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w; }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int i0 = 0; i0 < MT; i0 += IB) {
+      // output offsets + all residual loads of IB row tiles in flight at once (see epilogue_vec)
+      long long yo[IB][2];
+      float rr[IB][2][8];
+      bool ok[IB][2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) scratch[mfma32_row(r, lane) * EPI_PITCH + (lane & 31)] = acc[i][j][r];
+      for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
-      for (int ps = 0; ps < 2; ++ps) {
-        const int prow = ps * 16 + prow0;
-        const int m = m_base + i * 32 + prow;
-        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(scratch + prow * EPI_PITCH + c8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(scratch + prow * EPI_PITCH + c8 + 4);
-        if (m < p.M && nok) {
-          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-          const int img = m / p.HoWo, pix = m - img * p.HoWo;
+        for (int ps = 0; ps < 2; ++ps) {
+          const int m = m_base + (i0 + ii) * 32 + ps * 16 + prow0;
+          ok[ii][ps] = m < p.M && nok;
+          const int mm = m < p.M ? m : 0;
+          const int img = mm / p.HoWo, pix = mm - img * p.HoWo;
           const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
+          yo[ii][ps] = (long long)img * p.y_ns + (long long)oh * p.y_rs + (long long)ow * p.y_ps;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = v[q] * sc[q] + bi[q];
-          if (p.res) {
+          for (int q = 0; q < 8; ++q) rr[ii][ps][q] = 0.f;
+          if (p.res && ok[ii][ps] && (PREFETCH || IB * 2 == 2)) {     // MT > 2: one pass ahead only (register budget)
             const long long ro = (long long)img * p.r_ns + (long long)oh * p.r_rs + (long long)ow * p.r_ps;
             if (p.r_fmt) {
               const unsigned char *rq = reinterpret_cast<const unsigned char *>(p.res + ro) + (n >> 5) * 128 + (n & 31) * 2;
               const half8_t rh = *reinterpret_cast<const half8_t *>(rq), rl = *reinterpret_cast<const half8_t *>(rq + 64);
 #pragma unroll
-              for (int q = 0; q < 8; ++q) v[q] += (float)rh[q] + (float)rl[q];
+              for (int q = 0; q < 8; ++q) rr[ii][ps][q] = (float)rh[q] + (float)rl[q];
             } else {
               const f32x4 a = *reinterpret_cast<const f32x4 *>(p.res + ro + n), b = *reinterpret_cast<const f32x4 *>(p.res + ro + n + 4);
-              v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+              rr[ii][ps][0] = a.x; rr[ii][ps][1] = a.y; rr[ii][ps][2] = a.z; rr[ii][ps][3] = a.w;
+              rr[ii][ps][4] = b.x; rr[ii][ps][5] = b.y; rr[ii][ps][6] = b.z; rr[ii][ps][7] = b.w;
             }
           }
-          half8_t hi, lo;
+        }
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const float t = p.relu_out ? fmaxf(v[q], 0.f) : v[q];
-            hi[q] = (_Float16)t;
-            lo[q] = (_Float16)(t - (float)hi[q]);
+      for (int ii = 0; ii < IB; ++ii) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scratch[mfma32_row(r, lane) * EPI_PITCH + (lane & 31)] = acc[i0 + ii][j][r];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int prow = ps * 16 + prow0;
+          const f32x4 v0 = *reinterpret_cast<const f32x4 *>(scratch + prow * EPI_PITCH + c8);
+          const f32x4 v1 = *reinterpret_cast<const f32x4 *>(scratch + prow * EPI_PITCH + c8 + 4);
+          if (ok[ii][ps]) {
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            half8_t hi, lo;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              float t = v[q] * sc[q] + bi[q];
+              t += rr[ii][ps][q];
+              t = p.relu_out ? fmaxf(t, 0.f) : t;
+              hi[q] = (_Float16)t;
+              lo[q] = (_Float16)(t - (float)hi[q]);
+            }
+            unsigned char *yq = reinterpret_cast<unsigned char *>(p.y + yo[ii][ps]) + (n >> 5) * 128 + (n & 31) * 2;
+            *reinterpret_cast<half8_t *>(yq) = hi;
+            *reinterpret_cast<half8_t *>(yq + 64) = lo;
           }
-          unsigned char *yq = reinterpret_cast<unsigned char *>(p.y + (long long)img * p.y_ns + (long long)oh * p.y_rs + (long long)ow * p.y_ps) + (n >> 5) * 128 + (n & 31) * 2;
-          *reinterpret_cast<half8_t *>(yq) = hi;
-          *reinterpret_cast<half8_t *>(yq + 64) = lo;
         }
       }
     }

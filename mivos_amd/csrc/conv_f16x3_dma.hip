@@ -115,6 +115,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
 #pragma unroll
     for (int j = 0; j < A_LD; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(size_t)(lds0 + stage * A_STAGE + j * 8192), 16, voff_a[j], soff, 0, 0);
+    if (ABL == 7) return;                  // ablation: constant source offsets (no scalar tap / slab bookkeeping)
     a_tap_off += pix_step;
     if (++a_kw == p.KW) { a_kw = 0; a_tap_off += row_step; }
     if (++a_tap == ntaps) { a_tap = 0; a_tap_off = 0; a_slab_off += ROWB; }
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
 #pragma unroll
     for (int j = 0; j < B_LD; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(size_t)(lds0 + B_BASE + stage * B_STAGE + j * 8192), 16, voff_b[j], b_off, 0, 0);
-    b_off += b_step;
+    if (ABL != 7) b_off += b_step;
   };
 
   // ---- fragment addressing: per-lane bases once, stages / tiles by immediates ---------------------------
@@ -204,6 +205,8 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
   typedef std::false_type steady;
   typedef std::true_type tail;
 
+  long long t_start = 0;
+  if (ABL == 8) t_start = __builtin_readcyclecounter();      // profiling: shader cycles of the main loop / epilogue of workgroup 0
   issue_a(0);
   if (ABL != 1) issue_b(0);
   if (nk > 1) issue_a(1);
@@ -228,6 +231,10 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
     if (kt + 5 < nk) step(kt + 5, integral_constant<int, 5>{}, tail{});
   }
   if (wave < 4) phase_barrier();         // G0 waits for G1's last phase; the LDS stages are dead after this
+  if (ABL == 8 && blockIdx.x == 0 && tid == 0) {
+    reinterpret_cast<long long *>(p.ws)[0] = __builtin_readcyclecounter() - t_start;
+    reinterpret_cast<long long *>(p.ws)[1] = nk;
+  }
   if (p.kt_split) {                      // raw fp32 partial tile of this K slice: [slice][M][Cout], dense
     ConvP q = p;
     q.scale = q.bias = q.res = nullptr;
@@ -238,8 +245,10 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
     epilogue_vec<MT, NT>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, q, m0 + wm * TM, n0 + wn * TN, lane);
     return;
   }
-  if (p.y_fmt && p.split == p.Cout) epilogue_sh32<MT, NT>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
-  else if (p.vec_epi) epilogue_vec<MT, NT>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
+  // tiles that fit two workgroups per CU (<= 80 KB LDS) must also stay within 128 VGPRs: prefetch one row tile at a time
+  constexpr int EIB = (3 * BM + 2 * BN) * ROWB <= 80 * 1024 ? 1 : (MT > 2 ? 1 : MT);
+  if (p.y_fmt && p.split == p.Cout) epilogue_sh32<MT, NT, EIB>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
+  else if (p.vec_epi) epilogue_vec<MT, NT, EIB>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
   else epilogue_scalar<MT, NT>(acc, p, m0 + wm * TM, n0 + wn * TN, lane);
 #endif
 }
@@ -335,7 +344,7 @@ static int launch_pp(ConvP &p, hipStream_t st) {
   const int nk = (p.Cin >> 5) * p.KH * p.KW, wgs = tiles_m * p.tiles_n, cap = lds <= 80 * 1024 ? 512 : 256;
   int slices = 1;
   static const int thr6 = getenv("MIVOS_PP_SPLIT_THR") ? atoi(getenv("MIVOS_PP_SPLIT_THR")) : 4;   // tuning only: split when fewer than thr6/6 of the workgroup slots are filled (A/B: +0.7 % end to end vs 2)
-  if (p.vec_epi && p.ws && wgs * 6 <= cap * thr6 && nk >= 16) {
+  if (p.vec_epi && p.ws && wgs * 6 <= cap * thr6 && nk >= (wgs * 3 <= cap ? 16 : 96)) {   // nearly full grids: only very long K
     slices = cap / wgs < 2 ? 2 : cap / wgs;
     if (slices > 8) slices = 8;
     if (slices > nk / 8) slices = nk / 8;
@@ -375,6 +384,8 @@ int launch_conv_f16x3_dma(ConvP &p, hipStream_t st) {
       if (abl == 1) return launch_pp<256, 256, 2, 4, 1>(p, st);
       if (abl == 2) return launch_pp<256, 256, 2, 4, 2>(p, st);
       if (abl == 3) return launch_pp<256, 256, 2, 4, 3>(p, st);
+      if (abl == 7) return launch_pp<256, 256, 2, 4, 7>(p, st);
+      if (abl == 8) return launch_pp<256, 256, 2, 4, 8>(p, st);
       return launch_pp<256, 256, 2, 4>(p, st);
     }
     case 21: return launch_pp<128, 256, 2, 4>(p, st);
