@@ -250,6 +250,10 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
   if (p.y_fmt && p.split == p.Cout) epilogue_sh32<MT, NT, EIB>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
   else if (p.vec_epi) epilogue_vec<MT, NT, EIB>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
   else epilogue_scalar<MT, NT>(acc, p, m0 + wm * TM, n0 + wn * TN, lane);
+  if (ABL == 8 && blockIdx.x == 0 && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    reinterpret_cast<long long *>(p.ws)[2] = __builtin_readcyclecounter() - t_start;
+  }
 #endif
 }
 
@@ -388,7 +392,11 @@ int launch_conv_f16x3_dma(ConvP &p, hipStream_t st) {
       if (abl == 8) return launch_pp<256, 256, 2, 4, 8>(p, st);
       return launch_pp<256, 256, 2, 4>(p, st);
     }
-    case 21: return launch_pp<128, 256, 2, 4>(p, st);
+    case 21: {
+      static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;   // profiling only
+      if (abl == 8) return launch_pp<128, 256, 2, 4, 8>(p, st);
+      return launch_pp<128, 256, 2, 4>(p, st);
+    }
     case 22: return launch_pp<128, 64, 4, 2>(p, st);
     default: return launch_pp<128, 128, 2, 4>(p, st);
   }

@@ -94,8 +94,8 @@ for name, n, h, w, cin, cout, k, s in SHAPES:
     if sh_io:
         y2 = ops.to_f32(out_a)
     if os.environ.get("MIVOS_ABL") == "8":
-        c = ws.view(torch.int64)[:2].cpu().tolist()
-        print(f"   workgroup 0: {c[0]} shader cycles for {c[1]} K steps = {c[0] / max(c[1], 1):.0f} cycles/step; kernel wall {t2 * 1e3:.1f} us")
+        c = ws.view(torch.int64)[:3].cpu().tolist()
+        print(f"   workgroup 0: K loop {c[0]} shader cycles for {c[1]} steps = {c[0] / max(c[1], 1):.0f} cycles/step; loop + epilogue {c[2]} cycles; kernel wall {t2 * 1e3:.1f} us")
     diff = float((y1 - y2).abs().max())
     print(f"{name:30s} M={m:7d} var {lib.mivos_conv2d_variant_f16x3(m, cout)}/{lib.mivos_conv2d_variant_pp(m, cout, k * k * cin // 32)}  reg {t1*1e3:8.1f} us {fl/t1/1e9:6.1f} TF/s | "
           f"dma {t2*1e3:8.1f} us {fl/t2/1e9:6.1f} TF/s  x{t1/t2:4.2f}  max|diff| {diff:.3g} (|y| max {float(y1.abs().max()):.3g})")
