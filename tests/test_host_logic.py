@@ -116,6 +116,38 @@ def test_c_abi_exports_every_declared_symbol():
     assert _lib.load().mivos_version() == 1
 
 
+def test_lds_dma_conv_host_side_geometry_and_tile_selection():
+    """Host logic of the precision-2 (LDS-DMA) convolution path that needs no GPU: Act geometry (SH32 tensors inside a
+    one-pixel zero border), packed-weight size, tile selection exported through the C ABI."""
+    from mivos_amd import ops
+    lib = _lib.load()
+    n, h, w, c = 2, 5, 7, 64
+    a = ops.Act(torch.zeros(n, h + 2, w + 2, c), n, h, w, c)
+    assert a.shape == (n, h, w, c)
+    assert a.strides() == ((h + 2) * (w + 2) * c, (w + 2) * c, c)                         # image, row, pixel (floats)
+    assert a.interior_ptr() - a.buf.data_ptr() == 4 * ((w + 2) * c + c)                   # pixel (0, 0) behind the border
+    sub = a[1:2]
+    assert sub.shape == (1, h, w, c) and sub.interior_ptr() - a.interior_ptr() == 4 * a.strides()[0]
+    with pytest.raises(_lib.MivosHipError):
+        ops.alloc_act(1, 4, 4, 48, torch.device("cpu"))                                    # 32-channel lines only
+    # weights: 128 zero bytes + one 128-byte hi|lo line per (K step of 32 channels x 1 tap, output channel)
+    assert lib.mivos_pack_weights_f16x3_dma_bytes(256, 3, 3, 256) == 128 + (256 // 32) * 9 * 256 * 128
+    assert lib.mivos_pack_weights_f16x3_dma_bytes(96, 1, 1, 64) == 128 + 2 * 96 * 128
+    # tiles: 128x64 for narrow layers, 128x256 only for long-K layers whose tiles fill whole rounds of 256 CUs, else 128x128
+    pp = lib.mivos_conv2d_variant_pp
+    assert pp(129600, 64, 18) == 22 and pp(129600, 32, 9) == 22
+    assert pp(129600, 256, 72) == 21                                                      # decoder 3x3: 1013 tiles = 3.96 rounds
+    assert pp(129600, 256, 2) == 20                                                       # 1x1 64->256: short K, two workgroups per CU
+    assert pp(8100, 512, 288) == 20                                                       # 128 tiles of 128x256 would fill half the chip
+    assert pp(32400, 200, 144) == 20                                                      # Cout not a multiple of 256
+    # a DMA-staged operand cannot be modified on load / SH32 outputs need the LDS-DMA kernels: refused before any launch
+    L = ops.ConvLayer.pack(torch.randn(64, 64, 3, 3), None, None, 1, 1)
+    with pytest.raises(_lib.MivosHipError):
+        ops.conv(a, L, relu_in=True)
+    with pytest.raises(_lib.MivosHipError):
+        ops.conv(torch.zeros(1, 5, 7, 64), L, out_act=True)
+
+
 def test_cpu_tensors_fail_loudly(synthetic_states):
     """No CPU fallback: the product path refuses to run without an MI355X."""
     p = PropagationNetwork()
