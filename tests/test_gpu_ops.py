@@ -185,6 +185,24 @@ def test_conv2d_lds_dma_path(case):
     assert err < max(2e-6, 6e-8 * (cin * k * k) ** 0.5)
 
 
+def test_sh32_pack_kernels_match_the_cpu_restatement_bitwise():
+    """mivos_pack_activation_sh32 / mivos_unpack_activation_sh32 / mivos_pack_weights_f16x3_dma vs oracle/sh32.py."""
+    from oracle import sh32
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 9, 13, 96, generator=g) * 3.0
+    for relu in (False, True):
+        a = ops.to_act(x.to(DEV), relu=relu)
+        assert torch.equal(a.buf.cpu().view(torch.int32), sh32.pack_activation(x, relu=relu).view(torch.int32))     # incl. zero border
+        assert torch.equal(ops.to_f32(a).cpu(), sh32.unpack_activation(a.buf.cpu()))
+    for cout, k, cin in [(40, 3, 64), (130, 1, 96)]:
+        w = torch.randn(cout, cin, k, k, generator=g) * 0.05
+        L = ConvLayer.pack(w, None, None, 1, k // 2).to(DEV)
+        wd, _ = L.dma()
+        mult, _ = L._f16x3_scale()
+        ref = sh32.pack_weights_dma(L.w.cpu(), mult)
+        assert wd.numel() == ref.numel() and torch.equal(wd.cpu(), ref)
+
+
 def test_conv2d_lds_dma_matches_register_staged_kernel_bitwise():
     """Same products, same accumulation order: the two f16x3 back-ends agree bit for bit (no split-K on either side)."""
     g = torch.Generator().manual_seed(77)

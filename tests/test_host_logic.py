@@ -148,6 +148,33 @@ def test_lds_dma_conv_host_side_geometry_and_tile_selection():
         ops.conv(torch.zeros(1, 5, 7, 64), L, out_act=True)
 
 
+def test_sh32_restatement_round_trip_and_layout():
+    """oracle/sh32.py (the CPU definition the HIP pack kernels are compared with on the GPU): hi + lo keeps 22 bits, the
+    border stays zero, a 128-byte line = 32 hi halves then 32 lo halves, weight lines are chunk-swizzled by (n >> 1) & 7."""
+    from oracle import sh32
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 5, 64, generator=g) * 7.0
+    buf = sh32.pack_activation(x)
+    assert buf.shape == (2, 5, 7, 64) and buf.dtype == torch.float32
+    assert float((sh32.unpack_activation(buf) - x).abs().max()) <= 2.0 ** -21 * float(x.abs().max())
+    edge = buf.clone()
+    edge[:, 1:-1, 1:-1] = 0
+    assert int(edge.view(torch.int32).abs().max()) == 0
+    line = buf[1, 2, 3].view(torch.float16)                     # pixel (1, 2) of image 1: 2 groups x (32 hi | 32 lo)
+    hi, lo = sh32.split_hi_lo(x[1, 1, 2])
+    assert torch.equal(line[0:32], hi[0:32]) and torch.equal(line[32:64], lo[0:32]) and torch.equal(line[64:96], hi[32:64])
+    assert torch.equal(sh32.pack_activation(x, relu=True), sh32.pack_activation(torch.relu(x)))
+    w = torch.randn(5, 1, 1, 32, generator=g)
+    packed = sh32.pack_weights_dma(w, 2.0).view(torch.float16)
+    assert int(packed[:64].view(torch.int16).abs().max()) == 0  # the zero line
+    whi, wlo = sh32.split_hi_lo(w * 2.0)
+    for n in range(5):
+        row = packed[64 + n * 64: 64 + (n + 1) * 64].view(8, 8)
+        for lc in range(8):
+            src = (wlo if lc >= 4 else whi)[n, 0, 0, (lc & 3) * 8:(lc & 3) * 8 + 8]
+            assert torch.equal(row[lc ^ ((n >> 1) & 7)], src)
+
+
 def test_cpu_tensors_fail_loudly(synthetic_states):
     """No CPU fallback: the product path refuses to run without an MI355X."""
     p = PropagationNetwork()
