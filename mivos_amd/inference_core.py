@@ -16,6 +16,8 @@ pad, k, t, h, w, nh, nw``), re-designed around the HIP engine:
 """
 from collections import namedtuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -116,7 +118,7 @@ class InferenceCore:
             self.image_buf[idx] = self.images[:, idx].to(self.device)
         return self.image_buf[idx]
 
-    QUERY_BATCH = 8      # frames encoded together on a cache miss (when the cache has room for them)
+    QUERY_BATCH = int(os.environ.get("MIVOS_QUERY_BATCH", "16"))      # frames encoded together on a cache miss (when the cache has room)
 
     def _query(self, idx, upcoming=()):
         """Cached query features of frame idx.  On a miss the next not-yet-cached frames of the running pass
