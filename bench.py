@@ -181,7 +181,7 @@ def main():
     ap.add_argument("--mem-freq", type=int, default=5)
     ap.add_argument("--cpu-frames", type=int, default=2, help="propagated frames of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--profile-every", type=int, default=7,
-                    help="HIP-event sample every n-th timed step (0 = off); co-prime with InferenceCore.QUERY_BATCH (16) "
+                    help="HIP-event sample every n-th timed step (0 = off); co-prime with InferenceCore.QUERY_BATCH "
                          "so the samples see every phase of the batched query encoding")
     args = ap.parse_args()
 
