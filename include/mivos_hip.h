@@ -105,7 +105,8 @@ int mivos_pack_weights_f16x3(const float *w, void *out, int Cout, int KH, int KW
  * SH32 activation layout: N x H x W x C, C % 32 == 0; per pixel and group of 32 channels one 128-byte line =
  * 32 fp16 hi parts then 32 fp16 lo parts (x ~= hi + lo); strides are the fp32 ones (pixel stride C floats).
  * Precision 2 reads its input with im2col offsets and NO padding masks: every image must be stored with a
- * border of >= pad zero pixels (x_border), addressed through x_rstride / x_nstride.
+ * border of >= pad zero pixels (x_border), addressed through x_rstride / x_nstride; the (bordered) tensor and the
+ * packed weights must each be smaller than 2 GB (32-bit buffer offsets), pointers 128-byte aligned.
  * mivos_pack_activation_sh32 converts a strided fp32 NHWC tensor into a strided SH32 tensor (e.g. the interior of a
  * zero-bordered buffer), optionally through ReLU (the consumer cannot apply relu_in on DMA-staged data).
  * mivos_pack_weights_f16x3_dma: OHWI fp32 -> 128 zero bytes + [K step][Cout][128 B] hi|lo lines, chunk-swizzled
