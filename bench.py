@@ -1,24 +1,30 @@
 #!/usr/bin/env python
-"""Benchmark of the MI355X propagation + fusion engine (BASELINE.json metric: propagated frames/sec,
-DAVIS-2017 480p multi-object).
+"""Benchmark of the MI355X propagation + fusion engine (BASELINE.json metric: propagated frames/sec).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--objects 5] [--height 480 --width 854]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
 
-One "step" = one propagated frame = one iteration of the reference's do_pass loop
-(`inference_core.py:165`): query features (cached per frame), per-object top-k memory read, mask decoder,
-aggregation, memorize into the bank, and — on the second interaction — difference-aware fusion.
-Workload (BASELINE config 3): one synthetic 480x854 clip per GPU, K objects, top_k=50, mem_freq=5;
-`interact(mask, 0)` propagates T-1 frames, `interact(mask, T-1)` re-propagates T-2 frames with fusion.
-T is sized so that the session has >= warmup + steps propagated frames; the timed region is exactly
-`steps` of them, bracketed by barrier + torch.cuda.synchronize().  All inputs are resident in HBM
-before the timed region (mem_profile 0).  Multi-GPU: sequences shard (one clip per rank, no data-path
-collective), value = frames of all ranks / max-over-ranks time, scaling = weak.
+One "step" = one propagated frame = one iteration of the reference's do_pass loop (`inference_core.py:165`): query
+features (cached per frame), per-object top-k memory read, mask decoder, aggregation, memorize into the bank and - between
+two interacted frames - difference-aware fusion.
+
+Workloads (fixed, `--steps/--warmup` only choose WHICH steps are timed):
+  --config 3 (default; BASELINE config 3, the one the metric is quoted on): 480x854 clip of 70 frames, K=5 objects,
+             top_k=50, mem_freq=5; a session = interact(0) [69 plain frames] + interact(69) [68 fused frames] = 137 steps,
+             repeated with a fresh InferenceCore while more steps are requested.
+  --config 2: 480x854, 70 frames, K=1, top_k=20: session = interact(0) = 69 steps.
+  --config 5: 1080x1920, K=3, `--frames` (default 1000) frames, unbounded bank (mem_freq=5 -> T grows to 200): one session.
+  --config 4: synthetic YouTube-VOS-like suite (`--clips` of the 474 clips; lengths 5*U{4..36}, K~U{1..5}) sharded over
+             the ranks by mivos_amd.eval_suite; strong scaling over the fixed suite.
+Timed region: exactly `--steps` steps after `--warmup` untimed ones, bracketed by barrier + torch.cuda.synchronize(); at
+its start every query feature that was encoded ahead of its frame's turn is dropped (`prepaid_frames: 0`).  Inputs are
+resident in HBM before the clock starts.  Multi-GPU: one process per GPU; `python bench.py --gpus N` spawns its own ranks
+through torch.distributed.run when it was not launched by it.  Configs 2/3/5: one clip per rank (weak scaling); config 4:
+the suite is split (strong scaling).  value = steps of all ranks / max-over-ranks time.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,12 +32,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
 # fp16 MFMA dense peak (2.5 PFLOP/s) / 3 MFMA products per algorithmic multiply-add of the error-compensated
 # f16x3 convolution = the roofline of that kernel in ALGORITHMIC (fp32-equivalent) FLOP/s
 F16X3_PEAK_TFLOPS = 2500.0 / 3
+HBM_PEAK_GBS = 8000.0
 VARIANT_NAMES = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<64,64,2,2>",
                  2: "conv_igemm_kernel<128,32,4,1>", 3: "conv_igemm_kernel<128,64,2,2>", 4: "conv_cout1_kernel",
                  10: "conv_f16x3_kernel<128,128,2,2>", 11: "conv_f16x3_kernel<64,64,2,2>", 12: "conv_f16x3_kernel<128,32,4,1>",
@@ -39,41 +44,53 @@ VARIANT_NAMES = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<64,6
                  16: "conv_f16x3_pipe_kernel<128,256,2,4>", 17: "conv_f16x3_pipe_kernel<128,128,4,2>",
                  18: "conv_f16x3_pipe_kernel<64,256,2,4>", 19: "conv3x3_n32_direct_kernel",
                  20: "conv_f16x3_pp_kernel<128,128,2,4,0>", 21: "conv_f16x3_pp_kernel<128,256,2,4,0>",
-                 22: "conv_f16x3_pp_kernel<128,64,4,2,0>", 23: "conv_f16x3_pp_kernel<256,256,2,4,0>"}
+                 22: "conv_f16x3_pp_kernel<128,64,4,2,0>", 23: "conv_f16x3_pp_kernel<256,256,2,4,0>",
+                 30: "fusion_net_kernel", 90: "memread_select_kernel", 91: "memread_finalize_kernel"}
+CONFIGS = {
+    2: dict(name="davis480p_single_object", height=480, width=854, frames=70, objects=1, top_k=20, interactions=(0,)),
+    3: dict(name="davis480p_multiobject_fusion", height=480, width=854, frames=70, objects=5, top_k=50, interactions=(0, -1)),
+    5: dict(name="hd1080p_long_clip_unbounded_bank", height=1080, width=1920, frames=1000, objects=3, top_k=50, interactions=(0,)),
+}
 
 
-class StepTimer:
-    """step_cb hook: synchronises + stamps the clock exactly at step `warmup` and `warmup + steps`."""
+class StepClock:
+    """step_cb hook: after `warmup` steps drops the look-ahead of the running core, synchronises and stamps t0; stamps
+    t1 after exactly `steps` more."""
 
-    def __init__(self, warmup, steps, profile_every, ops, shard):
-        self.warmup, self.steps, self.every, self.ops, self.shard = warmup, steps, profile_every, ops, shard
-        self.n, self.t0, self.t1, self.samples = 0, None, None, []
-        self._arm()
+    def __init__(self, warmup, steps, profile_every, ops, shard, torch):
+        self.warmup, self.steps, self.every, self.ops, self.shard, self.torch = warmup, steps, profile_every, ops, shard, torch
+        self.n, self.t0, self.t1, self.samples, self.core, self.dropped = 0, None, None, [], None, 0
 
-    def _arm(self):
+    def _stamp(self):
+        self.torch.cuda.synchronize()
+        self.shard.barrier()
+        self.torch.cuda.synchronize()
+        return time.perf_counter()
+
+    def arm(self):
         if self.n == self.warmup and self.t0 is None:
-            torch.cuda.synchronize()
-            self.shard.barrier()
-            torch.cuda.synchronize()
-            self.t0 = time.perf_counter()
+            if self.core is not None:
+                self.dropped = self.core.drop_lookahead()
+            self.t0 = self._stamp()
         timed = self.t0 is not None and self.t1 is None
-        # sample every `every`-th timed step with HIP events around each conv launch
+        # sample every `every`-th timed step with HIP events around each conv / memory-read launch
         self.ops.PROFILE = self.samples if (timed and self.every and (self.n - self.warmup) % self.every == 0) else None
 
     def __call__(self):
         self.n += 1
         if self.n == self.warmup + self.steps and self.t1 is None:
-            torch.cuda.synchronize()
-            self.shard.barrier()
-            torch.cuda.synchronize()
-            self.t1 = time.perf_counter()
-        self._arm()
+            self.t1 = self._stamp()
+        self.arm()
+
+    @property
+    def done(self):
+        return self.t1 is not None
 
 
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench command, FETCH_SIZE x2 per the gfx950
-    correction of MI355X_MICROARCH.md §HBM).  None if no committed measurement matches."""
+    """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench command, FETCH_SIZE x2 per the gfx950 correction of
+    MI355X_MICROARCH.md §HBM).  None if no committed measurement matches."""
     import glob
     import re
     key = re.sub(r"[ ,]", "", kernel_name)
@@ -91,10 +108,9 @@ def pmc_traffic(kernel_name):
     return None
 
 
-def event_pair_overhead():
+def event_pair_overhead(torch):
     """Seconds a HIP-event pair measures around NOTHING on a busy stream (timestamp writes + command-processor gaps):
-    subtracted from every per-launch sample so that short launches (50 us) are not inflated by 10-15 %.  Calibrated with
-    a kernel in front of every pair, as in the sampled steps."""
+    subtracted from every per-launch sample so that short launches (50 us) are not inflated by 10-15 %."""
     x = torch.zeros(1 << 20, device="cuda")
     pairs = []
     for _ in range(64):
@@ -108,144 +124,288 @@ def event_pair_overhead():
     return t[len(t) // 2] * 1e-3
 
 
-def conv_roofline(samples, overhead=0.0):
-    """Aggregate the HIP-event samples per kernel instantiation; the dominant one is the roofline kernel."""
+def kernel_rooflines(samples, overhead=0.0):
+    """Aggregate the HIP-event samples per kernel instantiation.  Returns (dominant conv kernel's roofline record, the
+    memory-read affinity record, per-kernel table)."""
     agg = {}
     for variant, flops, e0, e1, shape in samples:
         a = agg.setdefault(variant, [0.0, 0.0, 0, 0.0])
         a[0] += flops
         a[1] += max(e0.elapsed_time(e1) * 1e-3 - overhead, 1e-7)
         a[2] += 1
-        m, cin, cout, k, stride, has_res = shape
-        # one read of the fp32 input, the (hi, lo) fp16 weights and the residual, one write of the fp32 output
-        a[3] += 4.0 * m * stride * stride * cin + 4.0 * cout * k * k * cin + 4.0 * m * cout * (2 if has_res else 1)
+        if variant < 90:
+            m, cin, cout, k, stride, has_res = shape
+            # one read of the input, the weights and the residual, one write of the output (4 B per element)
+            a[3] += 4.0 * m * stride * stride * cin + 4.0 * cout * k * k * cin + 4.0 * m * cout * (2 if has_res else 1)
+        else:
+            a[3] += shape[-1]
     if not agg:
-        return None, {}
+        return None, None, {}
+    total = sum(x[1] for x in agg.values())
     table = {VARIANT_NAMES[v]: dict(launches=a[2], avg_us=round(a[1] / a[2] * 1e6, 2), tflops=round(a[0] / a[1] / 1e12, 2),
-                                    time_share=round(a[1] / sum(x[1] for x in agg.values()), 3)) for v, a in sorted(agg.items())}
-    dom = max(agg.items(), key=lambda kv: kv[1][1])
-    v, (flops, secs, n, abytes) = dom
-    ach = flops / secs / 1e12
-    peak = F16X3_PEAK_TFLOPS if v >= 10 else MFMA_F32_PEAK_TFLOPS
-    roof = dict(bound="mfma", kernel=VARIANT_NAMES[v], achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
-                frac=round(ach / peak, 4), traffic=pmc_traffic(VARIANT_NAMES[v]), launches_sampled=n,
-                peak_note=("algorithmic (fp32-equivalent) FLOP/s; kernel issues 3 fp16 MFMA products per term: 2500/3"
-                           if v >= 10 else "fp32 MFMA dense peak"),
-                avg_launch_us=round(secs / n * 1e6, 2), algorithmic_gflop_per_launch=round(flops / n / 1e9, 3),
-                algorithmic_bytes_per_launch=int(abytes / n))
-    return roof, table
+                                    time_share=round(a[1] / total, 3)) for v, a in sorted(agg.items())}
+    roof = None
+    convs = {v: a for v, a in agg.items() if v < 90}
+    if convs:
+        v, (flops, secs, n, abytes) = max(convs.items(), key=lambda kv: kv[1][1])
+        ach = flops / secs / 1e12
+        peak = F16X3_PEAK_TFLOPS if v >= 10 else MFMA_F32_PEAK_TFLOPS
+        roof = dict(bound="mfma", kernel=VARIANT_NAMES[v], achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
+                    frac=round(ach / peak, 4), traffic=pmc_traffic(VARIANT_NAMES[v]), launches_sampled=n,
+                    peak_note=("algorithmic (fp32-equivalent) FLOP/s; kernel issues 3 fp16 MFMA products per term: 2500/3"
+                               if v >= 10 else "fp32 MFMA dense peak"),
+                    avg_launch_us=round(secs / n * 1e6, 2), algorithmic_gflop_per_launch=round(flops / n / 1e9, 3),
+                    algorithmic_bytes_per_launch=int(abytes / n))
+    aff = None
+    if 90 in agg:
+        flops, secs, n, abytes = agg[90]
+        ach = flops / secs / 1e12
+        aff = dict(bound="mfma", kernel="memread_select_kernel (exact fp32 MFMA affinity + streaming top-k)",
+                   achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                   traffic=pmc_traffic("memread_select_kernel"), launches_sampled=n, avg_launch_us=round(secs / n * 1e6, 2),
+                   algorithmic_gflop_per_launch=round(flops / n / 1e9, 3), algorithmic_bytes_per_launch=int(abytes / n),
+                   hbm_gbs_algorithmic=round(abytes / secs / 1e9, 1),
+                   note="FLOP = 2*K*n_mem*n_q*128 of the affinity matmul only; bytes = keys + queries read once")
+        if 91 in agg:
+            f2, s2, n2, b2 = agg[91]
+            aff["finalize"] = dict(kernel="memread_finalize_kernel (merge + softmax + sparse value gather)", avg_launch_us=round(s2 / n2 * 1e6, 2),
+                                   algorithmic_bytes_per_launch=int(b2 / n2), achieved_gbs=round(b2 / s2 / 1e9, 1),
+                                   frac_of_hbm_peak=round(b2 / s2 / 1e9 / HBM_PEAK_GBS, 4))
+    return roof, aff, table
 
 
-def cpu_baseline(images, gt, k, top_k, mem_freq, engine_masks, frames, with_fp64=True):
-    """The CPU oracle (restatement of the reference, oracle/stm_oracle.py) on a bounded sample of the same
-    workload: the first `frames` propagated frames of the first interaction.  Parity is reported three ways:
-    engine vs the fp32 oracle, and - because the algorithm is closed-loop and discontinuous (argmax / top-k
-    on an untrained network) - both of them against an fp64 run of the same oracle, which is the
-    noise floor any fp32 implementation of the reference has on this clip."""
-    from oracle import stm_oracle as O
-    from mivos_amd.util import synthetic
+def mean_iou(a, b, k):
     from mivos_amd.util.tensor_util import compute_np_iou
-    # oneDNN/OpenMP scale poorly past a few dozen threads on these small convolutions (256 threads on the
-    # 256-core host of the GPU box were 10x slower than 8 threads): use min(32, cores) and say so
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    return round(float(sum(compute_np_iou(a == j, b == j) for j in range(1, k + 1)) / k), 6)
+
+
+def cpu_baseline(torch, cfg, images, gt, mem_freq, prop, fuse, dev, n_frames, with_fp64):
+    """The CPU oracle (oracle/stm_oracle.py — bit-identical to the unmodified reference on this torch build, see
+    tests/test_oracle_golden.py and oracle/make_golden.py; /root/reference itself does not exist on the GPU box) on a
+    bounded sample of the same workload, and the engine on the same sample for parity.  Sample: a mini session on the first
+    `n_frames` frames of the clip with the workload's interaction pattern (so config 3 times fused frames too)."""
+    from oracle import stm_oracle as O
+    from mivos_amd.inference_core import InferenceCore
+    from mivos_amd.util import synthetic
+    k, top_k = cfg["objects"], cfg["top_k"]
+    torch.set_num_threads(min(32, os.cpu_count() or 1))      # oneDNN/OpenMP scale poorly past a few dozen threads here
     sd, fsd = synthetic.make_prop_state(0), synthetic.make_fuse_state(0)
-    core = O.OracleCore(sd, fsd, images[:, :frames + 1], k, mem_freq=mem_freq, top_k=top_k)
+    sub, sgt = images[:, :n_frames].cpu(), gt[:n_frames].cpu()
+    order = [0] + ([n_frames - 1] if len(cfg["interactions"]) > 1 else [])
+    core = O.OracleCore(sd, fsd, sub, k, mem_freq=mem_freq, top_k=top_k)
     t0 = time.perf_counter()
-    ref = core.interact(gt[0], 0)
+    for idx in order:
+        ref = core.interact(sgt[idx], idx)
     dt = time.perf_counter() - t0
-
-    def miou(a, b):
-        return round(float(sum(compute_np_iou(a == j, b == j) for j in range(1, k + 1)) / k), 6)
-
-    eng = engine_masks[:frames + 1]
-    parity = dict(frames=frames, mean_iou_engine_vs_ref_fp32=miou(eng[1:], ref[1:]),
-                  mismatching_pixel_fraction=round(float((eng[1:] != ref[1:]).mean()), 6))
+    eng = InferenceCore(prop, fuse, sub, k, mem_freq=mem_freq, device=dev)
+    for idx in order:
+        out = eng.interact(sgt[idx], idx)
+    inner = slice(1, n_frames - 1) if len(order) > 1 else slice(1, n_frames)
+    parity = dict(frames_compared=int(out[inner].shape[0]), mean_iou_engine_vs_ref_fp32=mean_iou(out[inner], ref[inner], k),
+                  mismatching_pixel_fraction=round(float((out[inner] != ref[inner]).mean()), 6),
+                  max_abs_dprob=round(float((eng.prob.cpu() - core.prob).abs().max()), 6))
     if with_fp64:
-        c64 = O.OracleCore(sd, fsd, images[:, :frames + 1], k, mem_freq=mem_freq, top_k=top_k, dtype=torch.float64)
-        r64 = c64.interact(gt[0], 0)
-        parity.update(mean_iou_ref_fp32_vs_ref_fp64=miou(ref[1:], r64[1:]), mean_iou_engine_vs_ref_fp64=miou(eng[1:], r64[1:]))
-    return dict(value=round(frames / dt, 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"first {frames} propagated frames of the same clip ({k} objects, no fusion), oracle/stm_oracle.py on PyTorch-CPU fp32",
-                seconds=round(dt, 2)), parity
+        c64 = O.OracleCore(sd, fsd, sub, k, mem_freq=mem_freq, top_k=top_k, dtype=torch.float64)
+        for idx in order:
+            r64 = c64.interact(sgt[idx], idx)
+        parity.update(mean_iou_ref_fp32_vs_ref_fp64=mean_iou(ref[inner], r64[inner], k), mean_iou_engine_vs_ref_fp64=mean_iou(out[inner], r64[inner], k),
+                      max_abs_dprob_ref_fp32_vs_fp64=round(float((core.prob.double() - c64.prob).abs().max()), 6),
+                      max_abs_dprob_engine_vs_fp64=round(float((eng.prob.cpu().double() - c64.prob).abs().max()), 6))
+    fused = core.propagated - (n_frames - 1) if len(order) > 1 else 0
+    return dict(value=round(core.propagated / dt, 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"mini session on the first {n_frames} frames of the same clip ({k} objects, top_k={top_k}): interact at {order}, "
+                       f"{core.propagated} propagated frames ({fused} of them fused); oracle/stm_oracle.py on PyTorch-CPU fp32 "
+                       f"(oracle == unmodified reference bit-exactly on this torch build: tests/test_oracle_golden.py)",
+                seconds=round(dt, 2), host_cores=os.cpu_count()), parity
+
+
+def run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, mem_freq, warmup, steps, profile_every):
+    """Repeat the configuration's session (fresh InferenceCore over the HBM-resident clip) until `warmup + steps` steps
+    have run.  Returns (clock, masks of the first session's first interaction)."""
+    from mivos_amd.inference_core import InferenceCore
+    clock = StepClock(warmup, steps, profile_every, ops, shard, torch)
+    T = images.shape[1]
+    first = None
+    while not clock.done:
+        core = InferenceCore(prop, fuse, images, cfg["objects"], mem_profile=0, mem_freq=mem_freq, device=dev)
+        clock.core = core
+        clock.arm()
+        for i in cfg["interactions"]:
+            idx = i % T
+            out = core.interact(gt[idx], idx, step_cb=clock)
+            if first is None:
+                first = out.copy()
+        del core
+    ops.PROFILE = None
+    torch.cuda.synchronize()
+    return clock, first
+
+
+def self_spawn(args_list, n):
+    """`python bench.py --gpus N` without a torchrun environment: start N ranks (one per GPU) through
+    torch.distributed.run and pass their output through."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + args_list
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--objects", type=int, default=5)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--width", type=int, default=854)
-    ap.add_argument("--top-k", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 8 sessions of configs 2/3, the whole clip of config 5)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before (default: one session of configs 2/3, 8 steps of config 5)")
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5))
+    ap.add_argument("--frames", type=int, default=None, help="clip length override (config 5: default 1000)")
+    ap.add_argument("--objects", type=int, default=None)
+    ap.add_argument("--top-k", type=int, default=None)
     ap.add_argument("--mem-freq", type=int, default=5)
-    ap.add_argument("--cpu-frames", type=int, default=2, help="propagated frames of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--clips", type=int, default=48, help="config 4: how many of the 474 suite clips to run (474 = all)")
+    ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the CPU-oracle mini session (0 = skip; default 4, config 5: 2)")
+    ap.add_argument("--cpu-fp64", action="store_true", help="also run the fp64 oracle on the mini session (arbitration truth)")
+    ap.add_argument("--exact-f32-steps", type=int, default=None,
+                    help="steps of the extra exact-fp32-MFMA measurement (CONV_PRECISION='f32'); default one session for config 3, 0 otherwise")
     ap.add_argument("--profile-every", type=int, default=7,
-                    help="HIP-event sample every n-th timed step (0 = off); co-prime with InferenceCore.QUERY_BATCH "
-                         "so the samples see every phase of the batched query encoding")
+                    help="HIP-event sample every n-th timed step (0 = off); co-prime with InferenceCore.QUERY_BATCH")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_spawn(sys.argv[1:], args.gpus))
+
+    import torch
     torch.set_grad_enabled(False)
     from mivos_amd import ops, shard
-    from mivos_amd.inference_core import InferenceCore
     from mivos_amd.model.fusion_net import FusionNet
     from mivos_amd.model.propagation.prop_net import PropagationNetwork
     from mivos_amd.util import synthetic
 
     rank, world, local = shard.init_distributed()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
 
-    K, need = args.objects, args.warmup + args.steps
-    T = max(4, (need + 3 + 1) // 2)                       # session has 2T-3 propagated frames
-    prop, fuse = PropagationNetwork(top_k=args.top_k), FusionNet()
+    if args.config == 4:
+        return bench_suite(args, torch, ops, shard, rank, world, dev)
+
+    cfg = dict(CONFIGS[args.config])
+    for key, val in (("frames", args.frames), ("objects", args.objects), ("top_k", args.top_k)):
+        if val is not None:
+            cfg[key] = val
+    K, T = cfg["objects"], cfg["frames"]
+    session = sum((T - 1) if n == 0 else (T - 2) for n in range(len(cfg["interactions"])))
+    warmup = args.warmup if args.warmup is not None else (8 if args.config == 5 else session)
+    steps = args.steps if args.steps is not None else (session - warmup if args.config == 5 else 8 * session)
+    cpu_frames = args.cpu_frames if args.cpu_frames is not None else (2 if args.config == 5 else 4)
+    exact_steps = args.exact_f32_steps if args.exact_f32_steps is not None else (session - 8 if args.config == 3 else 0)
+
+    prop, fuse = PropagationNetwork(top_k=cfg["top_k"]), FusionNet()
     prop.load_state_dict(synthetic.make_prop_state(0))
     fuse.load_state_dict(synthetic.make_fuse_state(0))
-    images, gt = synthetic.synthetic_clip(T, args.height, args.width, K, seed=100 + rank)
-    core = InferenceCore(prop.eval(), fuse.eval(), images, K, mem_profile=0, mem_freq=args.mem_freq, device=dev)
+    prop, fuse = prop.to(dev).eval(), fuse.to(dev).eval()
+    if T * cfg["height"] * cfg["width"] > 70 * 480 * 864:
+        images, gt = synthetic.synthetic_clip_device(T, cfg["height"], cfg["width"], K, seed=100 + rank, device=dev)
+    else:
+        images, gt = synthetic.synthetic_clip(T, cfg["height"], cfg["width"], K, seed=100 + rank)
+        images, gt = images.to(dev), gt.to(dev)                # resident in HBM before the clock starts
 
-    timer = StepTimer(args.warmup, args.steps, args.profile_every, ops, shard)
-    masks_first = core.interact(gt[0], 0, step_cb=timer).copy()
-    core.interact(gt[T - 1], T - 1, step_cb=timer)
-    ops.PROFILE = None
-    torch.cuda.synchronize()
-    assert timer.t0 is not None and timer.t1 is not None and core.propagated_frames >= need, (core.propagated_frames, need)
-    elapsed = shard.max_over_ranks(timer.t1 - timer.t0, device=dev)
-    recs = shard.gather_records([dict(rank=rank, frames=args.steps, seconds=timer.t1 - timer.t0)])
+    clock, masks_first = run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, warmup, steps, args.profile_every)
+    elapsed = shard.max_over_ranks(clock.t1 - clock.t0, device=dev)
+    recs = shard.gather_records([dict(rank=rank, steps=steps, seconds=round(clock.t1 - clock.t0, 6))])
+    mem_gb = torch.cuda.max_memory_allocated() / 1e9
 
+    exact = None
+    if exact_steps > 0 and rank == 0 and world == 1:
+        old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f32"
+        c2, _ = run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, 8, exact_steps, 0)
+        ops.CONV_PRECISION = old
+        exact = dict(value=round(exact_steps / (c2.t1 - c2.t0), 3), unit="frames/s", ms_per_step=round((c2.t1 - c2.t0) / exact_steps * 1e3, 3),
+                     steps=exact_steps, warmup=8, dtype="f32 (every convolution on exact fp32 MFMA, CONV_PRECISION='f32')")
     if rank != 0:
         return
-    ev_overhead = event_pair_overhead()
-    roof, table = conv_roofline(timer.samples, ev_overhead)
+    ev_overhead = event_pair_overhead(torch)
+    roof, aff, table = kernel_rooflines(clock.samples, ev_overhead)
     if roof is not None:
         roof["event_pair_overhead_us"] = round(ev_overhead * 1e6, 2)
+        roof["affinity"] = aff
     if os.environ.get("MIVOS_BENCH_SHAPES"):          # debug: per-shape conv time inside the timed region
         agg = {}
-        for variant, flops, e0, e1, shape in timer.samples:
-            a = agg.setdefault((variant,) + shape, [0.0, 0.0, 0])
+        for variant, flops, e0, e1, shape in clock.samples:
+            a = agg.setdefault((variant,) + tuple(shape), [0.0, 0.0, 0])
             a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
         tot = sum(a[1] for a in agg.values())
-        for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-            print(f"# {VARIANT_NAMES[key[0]]:38s} M={key[1]:7d} Cin={key[2]:4d} Cout={key[3]:4d} k={key[4]} s={key[5]}  n={a[2]:4d} "
-                  f"avg {a[1] / a[2] * 1e6:8.1f} us  {a[0] / a[1] / 1e12:6.1f} TF/s  share {a[1] / tot * 100:5.1f}%", file=sys.stderr)
-    out = dict(metric="propagated frames/sec, DAVIS-2017 480p multi-object", value=round(world * args.steps / elapsed, 3),
-               unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
-               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload=f"davis480p_multiobject_fusion: {args.height}x{args.width} clip of {T} frames per GPU, "
-                                    f"{K} objects, top_k={args.top_k}, mem_freq={args.mem_freq}, interact(0) then interact({T - 1}) "
-                                    f"(fused re-propagation); timed steps {args.warmup}..{args.warmup + args.steps} of {2 * T - 3}",
-                           objects=K, frames=T, height=args.height, width=args.width, top_k=args.top_k, mem_freq=args.mem_freq,
-                           plain_frames_timed=max(0, min(T - 1, need) - args.warmup), parallelism=f"sequence-sharded x{world}"),
-               roofline=roof, conv_kernels=table, per_rank=recs)
-    if world == 1 and args.cpu_frames > 0:
-        out["cpu_baseline"], out["parity"] = cpu_baseline(images, gt, K, args.top_k, args.mem_freq, masks_first, args.cpu_frames)
+        for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:48]:
+            print(f"# {VARIANT_NAMES[key[0]]:38s} {str(key[1:]):48s} n={a[2]:4d} avg {a[1] / a[2] * 1e6:8.1f} us  {a[0] / a[1] / 1e12:6.1f} TF/s  "
+                  f"share {a[1] / tot * 100:5.1f}%", file=sys.stderr)
+    metric = {2: "propagated frames/sec, DAVIS-2017 480p single-object", 3: "propagated frames/sec, DAVIS-2017 480p multi-object",
+              5: "propagated frames/sec, 1080p long clip"}[args.config]
+    inter = [i % T for i in cfg["interactions"]]
+    out = dict(metric=metric, value=round(world * steps / elapsed, 3), unit="frames/s", n_gpus=world, steps=steps, warmup=warmup,
+               ms_per_step=round(elapsed / steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f16x3 conv (fp16 hi+lo split operands, 3 fp16 MFMA products per term, fp32 accumulate) + exact f32 MFMA affinity/attention",
+               data="synthetic",
+               config=dict(workload=f"{cfg['name']} (BASELINE config {args.config}): {cfg['height']}x{cfg['width']} clip of {T} frames per GPU, {K} objects, "
+                                    f"top_k={cfg['top_k']}, mem_freq={args.mem_freq}; session = interact at frames {inter} = {session} steps "
+                                    f"({T - 1} plain" + (f" + {T - 2} fused" if len(inter) > 1 else "") + f"); timed steps {warmup}..{warmup + steps} of the repeated session",
+                           baseline_config=args.config, objects=K, frames=T, height=cfg["height"], width=cfg["width"], top_k=cfg["top_k"],
+                           mem_freq=args.mem_freq, session_steps=session, sessions_timed=round(steps / session, 3),
+                           prepaid_frames=0, lookahead_entries_dropped_at_t0=clock.dropped, parallelism=f"sequence-sharded x{world}"),
+               roofline=roof, conv_kernels=table, exact_f32=exact, hbm_peak_allocated_gb=round(mem_gb, 2), per_rank=recs)
+    if world == 1 and cpu_frames > 1:
+        out["cpu_baseline"], out["parity"] = cpu_baseline(torch, cfg, images, gt, args.mem_freq, prop, fuse, dev, cpu_frames, args.cpu_fp64)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
+
+
+def bench_suite(args, torch, ops, shard, rank, world, dev):
+    """--config 4: the synthetic YouTube-VOS-like suite, split over the ranks (strong scaling)."""
+    from mivos_amd import eval_suite as ES
+    from mivos_amd.inference_core import InferenceCore
+    from mivos_amd.model.fusion_net import FusionNet
+    from mivos_amd.model.propagation.prop_net import PropagationNetwork
+    from mivos_amd.util import synthetic
+    prop, fuse = PropagationNetwork(top_k=args.top_k or 50), FusionNet()
+    prop.load_state_dict(synthetic.make_prop_state(0))
+    fuse.load_state_dict(synthetic.make_fuse_state(0))
+    prop, fuse = prop.to(dev).eval(), fuse.to(dev).eval()
+    specs = ES.synthetic_suite(474)[:args.clips]
+
+    def factory(spec):
+        images, gt = synthetic.synthetic_clip_device(spec.frames, spec.height, spec.width, spec.objects, seed=spec.seed, device=dev)
+        return InferenceCore(prop, fuse, images, spec.objects, mem_profile=0, mem_freq=args.mem_freq, device=dev), gt[0]
+
+    ES.run_suite([ES.ClipSpec(-1, 12, 3, 480, 853, 7)], factory, 0, 1, sync=torch.cuda.synchronize)      # warm-up clip (untimed)
+    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    recs = ES.run_suite(specs, factory, rank, world, sync=torch.cuda.synchronize)
+    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
+    allrecs = shard.gather_records(recs)
+    if rank != 0:
+        return
+    s = ES.summarize(allrecs, len(specs))
+    per_rank = {}
+    for r in allrecs:
+        a = per_rank.setdefault(r["rank"], dict(rank=r["rank"], clips=0, frames=0, seconds=0.0))
+        a["clips"] += 1; a["frames"] += r["frames"]; a["seconds"] = round(a["seconds"] + r["seconds"], 4)
+    print(json.dumps(dict(
+        metric="propagated frames/sec, YouTube-VOS-like suite sharded over the GPUs", value=round(s["frames"] / elapsed, 3), unit="frames/s",
+        n_gpus=world, steps=s["frames"], warmup=11, ms_per_step=round(elapsed / s["frames"] * 1e3, 3), higher_is_better=True, scaling="strong",
+        vs_baseline=None, dtype="f16x3 conv (fp16 hi+lo split operands, 3 fp16 MFMA products per term, fp32 accumulate) + exact f32 MFMA affinity",
+        data="synthetic",
+        config=dict(workload=f"youtubevos_like_suite (BASELINE config 4): first {len(specs)} of 474 synthetic clips, lengths 5*U{{4..36}}, K~U{{1..5}}, 480x853, "
+                             f"interact(first frame); clips assigned longest-first to {world} rank(s), no data-path collective; clip generation (GPU) inside the timed region",
+                    baseline_config=4, clips=len(specs), parallelism=f"sequence-sharded x{world}", suite_checksum=s["checksum"]),
+        roofline=None, cpu_baseline=None, wall_seconds=round(elapsed, 3), busiest_rank_engine_seconds=round(s["busiest_rank_seconds"], 3),
+        per_rank=sorted(per_rank.values(), key=lambda r: r["rank"]))))
 
 
 if __name__ == "__main__":

@@ -146,14 +146,28 @@ int mivos_upsample2x_add(const float *skip, int64_t skip_nstride, const float *u
  *   qk     [n_q][128]              (shared by all objects, NOT pre-scaled; the kernel applies
  *                                   1/sqrt(128) exactly like prop_net.py:86)
  *   out    [n_obj][n_q] rows of 512 floats at out + o*out_ostride + q*out_pstride
- * workspace: mivos_memory_read_workspace_bytes() bytes of device scratch.
+ * workspace: mivos_memory_read_workspace_bytes() bytes of device scratch (the per-segment candidate lists).
  * Returns MIVOS_ERR_TOPK_RANGE when top_k > n_mem (reference raises).  top_k <= 64.
+ * The read is two launches, also callable one by one (profilers time the affinity/selection kernel alone):
+ *   mivos_memory_read_select   - persistent affinity + streaming top-k kernel, candidate lists -> workspace
+ *   mivos_memory_read_finalize - exact merge, softmax over the k survivors, value gather -> out
+ * mivos_memory_read_topk = select + finalize with the same arguments.
  * -------------------------------------------------------------------------------------------- */
 int64_t mivos_memory_read_workspace_bytes(int n_obj, int64_t n_mem, int n_q, int top_k);
 int mivos_memory_read_topk(const float *keys, int64_t keys_ostride, const float *values,
                            int64_t values_ostride, const float *qk, float *out, int64_t out_ostride,
                            int64_t out_pstride, int n_obj, int64_t n_mem, int n_q, int top_k,
                            void *workspace, int64_t workspace_bytes, void *stream);
+/* How the select kernel cuts the work (host logic, no GPU needed; tests / profilers): plan_out[6] = {workgroups, tiles of
+ * 32 memory positions per workgroup, candidate lists per stream, tiles per stream, streams (= n_obj * ceil(n_q / 64)),
+ * entries per list}.  Workgroup w takes tiles [w * tiles_per_wg, (w + 1) * tiles_per_wg) of the concatenated streams. */
+int mivos_memory_read_plan(int n_obj, int64_t n_mem, int n_q, int top_k, int32_t *plan_out);
+int mivos_memory_read_select(const float *keys, int64_t keys_ostride, const float *qk, int n_obj,
+                             int64_t n_mem, int n_q, int top_k, void *workspace, int64_t workspace_bytes,
+                             void *stream);
+int mivos_memory_read_finalize(const float *values, int64_t values_ostride, float *out,
+                               int64_t out_ostride, int64_t out_pstride, int n_obj, int64_t n_mem,
+                               int n_q, int top_k, void *workspace, int64_t workspace_bytes, void *stream);
 /* Debug/test export: same selection, but writes the k selected memory indices (ascending score
  * rank, best first) and their normalised softmax weights instead of the readout. */
 int mivos_memory_read_topk_indices(const float *keys, int64_t keys_ostride, const float *qk,
@@ -171,6 +185,14 @@ int mivos_memory_read_topk_indices(const float *keys, int64_t keys_ostride, cons
 int mivos_attention_align(const float *mk, const float *qk, const float *pos16, const float *neg16,
                           float *out, int n_obj, int n_pos, void *stream);
 
+/* Dense attention matrix W[o][m][q] = softmax over m of mk[o][m] . qk[q] / sqrt(128): AttentionMemory.forward /
+ * PropagationNetwork.get_W (prop_net.py:115-129, 183-185) and attn_network.py:12-28.  The propagation path never needs
+ * it (mivos_attention_align folds W into the pos/neg products); exported for callers that want W itself.
+ *   mk [n_obj][n_mem][128], qk [n_q][128] per object at qk + o*qk_ostride (0 = one query map shared by all objects),
+ *   w [n_obj][n_mem][n_q] dense. */
+int mivos_attention_weights(const float *mk, const float *qk, int64_t qk_ostride, float *w, int n_obj, int n_mem,
+                            int n_q, void *stream);
+
 /* ---- planar single-channel maps ------------------------------------------------------------- */
 
 /* F.interpolate(mode='area') to 1/16 resolution (prop_net.py:195-196): mean over 16x16 blocks. */
@@ -187,6 +209,11 @@ int mivos_aggregate_wbg(const float *prob, float *out, int K, int64_t P, int kee
 /* aggregate_sbg (model/aggregate.py:4-20): background fixed at 0.5. */
 int mivos_aggregate_sbg(const float *prob, float *out, int K, int64_t P, int keep_bg, int hard,
                         void *stream);
+/* aggregate_wbg_channel (model/aggregate.py:39-53; FusionNet training, fusion_model.py:87): prob [B][K][P] ->
+ * logits [B][K+1][P] (background first, log(p/(1-p)) of the clamped probabilities, x1000 when hard) and their softmax
+ * soft [B][K+1][P] (keep_bg=1) or [B][K][P].  Either output pointer may be NULL.  Any K >= 1. */
+int mivos_aggregate_wbg_channel(const float *prob, float *logits, float *soft, int B, int K, int64_t P,
+                                int keep_bg, int hard, void *stream);
 
 /* torch.argmax(prob, dim=0) -> uint8 (inference_core.py:259-260, :280); first index wins ties.
  * prob plane c at prob + c*plane_stride. */

@@ -49,12 +49,17 @@ PROTOTYPES = {
     "mivos_upsample2x_add": (C.c_int, [vp, i64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_memory_read_workspace_bytes": (i64, [C.c_int, i64, C.c_int, C.c_int]),
     "mivos_memory_read_topk": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
+    "mivos_memory_read_plan": (C.c_int, [C.c_int, i64, C.c_int, C.c_int, C.POINTER(i32)]),
+    "mivos_memory_read_select": (C.c_int, [vp, i64, vp, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
+    "mivos_memory_read_finalize": (C.c_int, [vp, i64, vp, i64, i64, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
     "mivos_memory_read_topk_indices": (C.c_int, [vp, i64, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
     "mivos_attention_align": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "mivos_area_pool16": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_resize_bilinear": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_aggregate_wbg": (C.c_int, [vp, vp, C.c_int, i64, C.c_int, C.c_int, vp]),
     "mivos_aggregate_sbg": (C.c_int, [vp, vp, C.c_int, i64, C.c_int, C.c_int, vp]),
+    "mivos_aggregate_wbg_channel": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, C.c_int, vp]),
+    "mivos_attention_weights": (C.c_int, [vp, vp, i64, vp, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_argmax_u8": (C.c_int, [vp, i64, vp, C.c_int, i64, vp]),
     "mivos_mask_diff": (C.c_int, [vp, vp, vp, vp, i64, vp]),
     "mivos_sigmoid": (C.c_int, [vp, vp, i64, vp]),

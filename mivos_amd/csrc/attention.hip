@@ -95,9 +95,65 @@ __global__ __launch_bounds__(256) void attention_align_kernel(const float *__res
   }
 }
 
+// ---- dense W (PropagationNetwork.get_W / AttentionMemory.forward, prop_net.py:115-129, 183-185) ----------------
+// W[obj][m][q] = softmax over m of mk[m].qk[q]/sqrt(128).  Not on the InferenceCore path (get_attention never
+// materialises W) but part of the module's public surface.  Two launches: a wave per 32x32 score tile writes the raw
+// affinities (fp32 MFMA, operands straight from L2), then one thread per query column normalises it in place
+// (max, sum of exp, divide: torch.softmax's formulation; consecutive threads = consecutive q => coalesced rows).
+__global__ __launch_bounds__(64) void affinity_tile_kernel(const float *__restrict__ mk, const float *__restrict__ qk,
+                                                          long long qk_ostride, float *__restrict__ w, int n_mem, int n_q) {
+  const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+  const int obj = blockIdx.z;
+  const int q0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int q = q0 + j, mrow = m0 + j;
+  const float *qrow = qk + (long long)obj * qk_ostride + (long long)(q < n_q ? q : n_q - 1) * ACK + 4 * h;
+  const float *arow = mk + ((long long)obj * n_mem + (mrow < n_mem ? mrow : n_mem - 1)) * ACK + 4 * h;
+  const float d = sqrtf((float)ACK);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 8 * u);
+    f32x4 b = *reinterpret_cast<const f32x4 *>(qrow + 8 * u);
+    b.x /= d; b.y /= d; b.z /= d; b.w /= d;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+  }
+  if (q < n_q) {
+    float *wb = w + (long long)obj * n_mem * n_q + q;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + mfma32_row(r, lane);
+      if (m < n_mem) wb[(long long)m * n_q] = acc[r];
+    }
+  }
+}
+
+__global__ void column_softmax_kernel(float *__restrict__ w, int n_mem, int n_q) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_q) return;
+  float *col = w + (long long)blockIdx.y * n_mem * n_q + q;
+  float mx = -INFINITY;
+  for (int m = 0; m < n_mem; ++m) mx = fmaxf(mx, col[(long long)m * n_q]);
+  float sum = 0.f;
+  for (int m = 0; m < n_mem; ++m) sum += expf(col[(long long)m * n_q] - mx);
+  for (int m = 0; m < n_mem; ++m) col[(long long)m * n_q] = expf(col[(long long)m * n_q] - mx) / sum;
+}
+
 }  // namespace mivos
 
 using namespace mivos;
+
+extern "C" int mivos_attention_weights(const float *mk, const float *qk, int64_t qk_ostride, float *w, int n_obj, int n_mem,
+                                       int n_q, void *stream) {
+  if (!mk || !qk || !w || n_obj < 1 || n_mem < 1 || n_q < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "attention_weights: bad arguments");
+  if (((uintptr_t)mk & 15) || ((uintptr_t)qk & 15) || (qk_ostride & 3)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "attention_weights: mk/qk must be 16-byte aligned");
+  hipLaunchKernelGGL(affinity_tile_kernel, dim3(cdiv(n_q, 32), cdiv(n_mem, 32), n_obj), dim3(64), 0, (hipStream_t)stream, mk, qk,
+                     (long long)qk_ostride, w, n_mem, n_q);
+  hipLaunchKernelGGL(column_softmax_kernel, dim3(cdiv(n_q, 64), n_obj), dim3(64), 0, (hipStream_t)stream, w, n_mem, n_q);
+  return check_launch("attention_weights");
+}
 
 extern "C" int mivos_attention_align(const float *mk, const float *qk, const float *pos16, const float *neg16, float *out,
                                      int n_obj, int n_pos, void *stream) {

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/mivos_hip.h"
 
 namespace mivos {
@@ -15,6 +17,20 @@ int fail(int code, const char *fmt, ...);
 inline int check_launch(const char *what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return MIVOS_OK;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device); `mask` holds one bit per
+// device (idempotent when two host threads race, so no lock is needed)
+inline int ensure_dynamic_lds(const void *kern, size_t lds, std::atomic<uint64_t> &mask, const char *what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "%s: hipGetDevice failed", what);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(mask.load(std::memory_order_acquire) & bit)) {
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+    mask.fetch_or(bit, std::memory_order_release);
+  }
   return MIVOS_OK;
 }
 

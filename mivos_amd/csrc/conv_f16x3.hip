@@ -615,12 +615,8 @@ static int launch_direct3x3(ConvP &p, hipStream_t st) {
   p.tiles_n = cdiv(p.Cout, BN);
   const size_t lds = (2ull * 10 * 34 * 40 + 2ull * 2 * BN * PITCH2) * sizeof(_Float16);
   auto kern = conv3x3_direct_kernel<BN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(conv3x3_direct): %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_mask{0};  // per instantiation, one bit per device
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_mask, "conv3x3_direct")) return rc;
   const int kpad4 = cdiv(p.Ktot, BKH) * BKH / 4;
   hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y * p.N * p.tiles_n), dim3(512), lds, st, p, kpad4, tiles_x, tiles_y);
   return check_launch("conv3x3_direct");
@@ -774,12 +770,8 @@ static int launch_n32_direct(ConvP &p, hipStream_t st) {
   const int tiles_x = cdiv(p.W, 32), tiles_y = cdiv(p.H, 8);
   const size_t lds = (2ull * 2 * 10 * 34 * (CIN + 8) + 2ull * 9 * 32 * (CIN + 8)) * sizeof(_Float16);
   auto kern = conv3x3_n32_direct_kernel<CIN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(conv3x3_n32_direct): %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_mask{0};  // per instantiation, one bit per device
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_mask, "conv3x3_n32_direct")) return rc;
   const int kpad4 = cdiv(p.Ktot, BKH) * BKH / 4;
   const int n_tiles = tiles_x * tiles_y * p.N;
   const int grid = n_tiles < 256 ? n_tiles : 256;            // persistent: one workgroup per CU walks the tiles
@@ -867,12 +859,8 @@ static int launch_f16x3(ConvP &p, hipStream_t st) {
   if (slices > 1) { p.kt_split = cdiv(nk, slices); slices = cdiv(nk, p.kt_split); p.partial = (float *)p.ws; }
   const size_t lds = 2ull * (BM + BN) * PITCH * sizeof(_Float16);
   auto kern = conv_f16x3_kernel<BM, BN, WGM, WGN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(conv_f16x3): %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_mask{0};  // per instantiation, one bit per device
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_mask, "conv_f16x3")) return rc;
   const int kpad4 = cdiv(p.Ktot, BKH) * BKH / 4;
   hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n, slices), dim3(256), lds, st, p, kpad4);
   if (slices > 1) return launch_splitk_reduce(p, slices, st);
@@ -885,12 +873,8 @@ static int launch_f16x3_pipe(ConvP &p, hipStream_t st) {
   p.tiles_n = cdiv(p.Cout, BN);
   const size_t lds = 2ull * 2 * (BM + BN) * PITCH2 * sizeof(_Float16);
   auto kern = conv_f16x3_pipe_kernel<BM, BN, WGM, WGN, ABL>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(conv_f16x3_pipe): %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_mask{0};  // per instantiation, one bit per device
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_mask, "conv_f16x3_pipe")) return rc;
   const int kpad4 = cdiv(p.Ktot, BKH) * BKH / 4;
   hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(512), lds, st, p, kpad4);
   return check_launch("conv_f16x3_pipe");

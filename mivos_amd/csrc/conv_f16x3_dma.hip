@@ -335,12 +335,8 @@ static int launch_pp(ConvP &p, hipStream_t st) {
   p.tiles_n = cdiv(p.Cout, BN);
   const size_t lds = (3ull * BM + 2ull * BN) * ROWB;
   auto kern = conv_f16x3_pp_kernel<BM, BN, WGM, WGN, ABL>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(conv_f16x3_pp): %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_mask{0};  // per instantiation, one bit per device
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_mask, "conv_f16x3_pp")) return rc;
   const long long x_bytes = ((long long)(p.N - 1) * p.x_ns + (long long)(p.H + 2 * p.pad - 1) * p.x_rs + (long long)(p.W + 2 * p.pad) * p.x_ps) * 4;
   const long long w_bytes = ROWB + (long long)(p.Cin >> 5) * p.KH * p.KW * p.Cout * ROWB;
   if (x_bytes >= 0x7ff00000ll || w_bytes >= 0x7ff00000ll) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d (SH32 input): tensor larger than 2 GB");

@@ -194,12 +194,8 @@ static int launch_igemm(ConvP &p, hipStream_t st) {
   p.tiles_n = cdiv(p.Cout, BN);
   const size_t lds = 2ull * (BM + BN) * LDK * sizeof(float);
   auto kern = conv_igemm_kernel<BM, BN, WGM, WGN>;
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "hipFuncSetAttribute(conv_igemm): %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_mask{0};  // per instantiation, one bit per device
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_mask, "conv_igemm")) return rc;
   hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(256), lds, st, p);
   return check_launch("conv_igemm");
 }

@@ -135,43 +135,70 @@ __global__ void area_pool16_kernel(const float *__restrict__ x, float *__restric
 }
 
 // ---------------------------------------------------------------- aggregate (soft background / fixed background)
-template <bool WBG>
-__global__ void aggregate_kernel(const float *__restrict__ prob, float *__restrict__ out, int K, int64_t P, int keep_bg,
-                                 int hard) {
+// prob [B][K][P] -> softmax over the K+1 logits log(p/(1-p)) (background first) -> out [B][K(+1)][P]; optionally the
+// logits themselves [B][K+1][P] (aggregate_wbg_channel).  CACHE: logits of up to 32 objects stay in registers; the
+// general variant recomputes them from prob in each of its three sweeps (same arithmetic, any K).
+__device__ __forceinline__ float clamped_logit(float p, int hard) {
+  const float c = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+  const float lg = logf(c / (1.f - c));
+  return hard ? lg * 1000.f : lg;
+}
+
+template <bool WBG, bool CACHE>
+__global__ void aggregate_kernel(const float *__restrict__ prob, float *__restrict__ out, float *__restrict__ logits, int B,
+                                 int K, int64_t P, int keep_bg, int hard) {
   constexpr int KMAX = 32;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
-    float l[KMAX + 1];
+  const int64_t total = (int64_t)B * P;
+  const int kout = keep_bg ? K + 1 : K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / P, px = i - b * P;
+    const float *pb = prob + b * K * P + px;
+    float *ob = out ? out + b * kout * P + px : nullptr;
+    float *lb = logits ? logits + b * (K + 1) * P + px : nullptr;
+    float l[CACHE ? KMAX + 1 : 1];
     float bg = WBG ? 1.f : 0.5f;
     float mx = -INFINITY;
 #pragma unroll 1
     for (int k = 0; k < K; ++k) {
-      const float pk = prob[(int64_t)k * P + i];
+      const float pk = pb[(int64_t)k * P];
       if (WBG) bg *= (1.f - pk);
-      const float c = fminf(fmaxf(pk, 1e-7f), 1.f - 1e-7f);
-      float lg = logf(c / (1.f - c));
-      if (hard) lg *= 1000.f;
-      l[k + 1] = lg;
+      const float lg = clamped_logit(pk, hard);
+      if (CACHE) l[k + 1] = lg;
+      if (lb) lb[(int64_t)(k + 1) * P] = lg;
       mx = fmaxf(mx, lg);
     }
-    {
-      const float c = fminf(fmaxf(bg, 1e-7f), 1.f - 1e-7f);
-      float lg = logf(c / (1.f - c));
-      if (hard) lg *= 1000.f;
-      l[0] = lg;
-      mx = fmaxf(mx, lg);
-    }
+    const float lbg = clamped_logit(bg, hard);
+    if (lb) lb[0] = lbg;
+    mx = fmaxf(mx, lbg);
+    if (!ob) continue;
     float sum = 0.f;
+    const float ebg = expf(lbg - mx);
+    sum += ebg;
 #pragma unroll 1
-    for (int k = 0; k <= K; ++k) {
-      l[k] = expf(l[k] - mx);
-      sum += l[k];
+    for (int k = 1; k <= K; ++k) {
+      const float e = expf((CACHE ? l[k] : clamped_logit(pb[(int64_t)(k - 1) * P], hard)) - mx);
+      if (CACHE) l[k] = e;
+      sum += e;
     }
-    if (keep_bg) {
-      for (int k = 0; k <= K; ++k) out[(int64_t)k * P + i] = l[k] / sum;
-    } else {
-      for (int k = 1; k <= K; ++k) out[(int64_t)(k - 1) * P + i] = l[k] / sum;
+    if (keep_bg) ob[0] = ebg / sum;
+    float *o1 = keep_bg ? ob + P : ob;
+#pragma unroll 1
+    for (int k = 1; k <= K; ++k) {
+      const float e = CACHE ? l[k] : expf(clamped_logit(pb[(int64_t)(k - 1) * P], hard) - mx);
+      o1[(int64_t)(k - 1) * P] = e / sum;
     }
   }
+}
+
+template <bool WBG>
+static int launch_aggregate(const float *prob, float *out, float *logits, int B, int K, int64_t P, int keep_bg, int hard,
+                            hipStream_t st, const char *what) {
+  if (!prob || (!out && !logits) || K < 1 || B < 1 || P < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "%s: bad arguments", what);
+  if (K <= 32)
+    hipLaunchKernelGGL((aggregate_kernel<WBG, true>), dim3(grid_for((int64_t)B * P)), dim3(256), 0, st, prob, out, logits, B, K, P, keep_bg, hard);
+  else
+    hipLaunchKernelGGL((aggregate_kernel<WBG, false>), dim3(grid_for((int64_t)B * P)), dim3(256), 0, st, prob, out, logits, B, K, P, keep_bg, hard);
+  return check_launch(what);
 }
 
 __global__ void argmax_u8_kernel(const float *__restrict__ prob, int64_t plane_stride, uint8_t *__restrict__ out,
@@ -282,15 +309,16 @@ extern "C" int mivos_resize_bilinear(const float *x, float *y, int planes, int h
 }
 
 extern "C" int mivos_aggregate_wbg(const float *prob, float *out, int K, int64_t P, int keep_bg, int hard, void *stream) {
-  if (!prob || !out || K < 1 || K > 32) return fail(MIVOS_ERR_INVALID_ARGUMENT, "aggregate_wbg: 1 <= K <= 32 required");
-  hipLaunchKernelGGL(aggregate_kernel<true>, dim3(grid_for(P)), dim3(256), 0, ST, prob, out, K, P, keep_bg, hard);
-  return check_launch("aggregate_wbg");
+  return launch_aggregate<true>(prob, out, nullptr, 1, K, P, keep_bg, hard, ST, "aggregate_wbg");
 }
 
 extern "C" int mivos_aggregate_sbg(const float *prob, float *out, int K, int64_t P, int keep_bg, int hard, void *stream) {
-  if (!prob || !out || K < 1 || K > 32) return fail(MIVOS_ERR_INVALID_ARGUMENT, "aggregate_sbg: 1 <= K <= 32 required");
-  hipLaunchKernelGGL(aggregate_kernel<false>, dim3(grid_for(P)), dim3(256), 0, ST, prob, out, K, P, keep_bg, hard);
-  return check_launch("aggregate_sbg");
+  return launch_aggregate<false>(prob, out, nullptr, 1, K, P, keep_bg, hard, ST, "aggregate_sbg");
+}
+
+extern "C" int mivos_aggregate_wbg_channel(const float *prob, float *logits, float *soft, int B, int K, int64_t P, int keep_bg,
+                                           int hard, void *stream) {
+  return launch_aggregate<true>(prob, soft, logits, B, K, P, keep_bg, hard, ST, "aggregate_wbg_channel");
 }
 
 extern "C" int mivos_argmax_u8(const float *prob, int64_t plane_stride, uint8_t *out, int planes, int64_t P, void *stream) {

@@ -1,0 +1,88 @@
+"""Suite runner: many independent clips, sharded over the GPUs of a node.
+
+The reference evaluates a dataset sequence by sequence with a fresh processor per sequence
+(`eval_interactive_davis.py:74-108`; the YouTube-VOS loader resizes every clip so that its short side is 480,
+`dataset/yv_test_dataset.py:102-109`).  Sequences never exchange data, so the multi-GPU form is: one process per GPU,
+weights replicated, clips assigned longest-first (``shard.assign_sequences``), NO data-path collective, one small
+``all_gather_object`` of per-clip records at the end.  This module is that loop for the MI355X engine:
+
+    specs   = synthetic_suite(474)                       # or any list of ClipSpec
+    records = run_suite(specs, engine_factory, rank, world)
+    summary = summarize(gather_records(records))
+
+``engine_factory(spec) -> (core, first_mask)`` builds the per-clip engine (an ``InferenceCore`` over the clip's
+frames) — injected so that the sharding logic is testable on CPU with a stub engine (tests/test_eval_suite_gloo.py).
+"""
+import time
+import zlib
+from collections import namedtuple
+
+import numpy as np
+
+from . import shard
+
+ClipSpec = namedtuple("ClipSpec", "clip_id frames objects height width seed")
+
+
+def yv_480p_size(h, w):
+    """Target size of the YouTube-VOS loader (yv_test_dataset.py:102-109): short side -> 480, the other side scaled
+    with integer floor division."""
+    return (h * 480 // w, 480) if h > w else (480, w * 480 // h)
+
+
+def synthetic_suite(n_clips=474, seed=0, source_sizes=((720, 1280),)):
+    """BASELINE config 4 restated as synthetic input: 474 clips (the size of YouTube-VOS-2018 val),
+    lengths 5 * U{4..36} frames, K ~ U{1..5} objects, source frames resized by the loader's rule (720x1280 -> 480x853)."""
+    r = np.random.RandomState(0xC0FFEE ^ seed)
+    specs = []
+    for i in range(n_clips):
+        h, w = source_sizes[int(r.randint(len(source_sizes)))]
+        th, tw = yv_480p_size(h, w)
+        specs.append(ClipSpec(i, int(5 * r.randint(4, 37)), int(r.randint(1, 6)), th, tw, 1000 + i))
+    return specs
+
+
+def mask_checksum(masks):
+    """Order-independent identity of a clip's output (uint8 [T,H,W]) for cross-run / cross-world-size comparisons."""
+    return int(zlib.crc32(np.ascontiguousarray(masks).tobytes()))
+
+
+def run_suite(specs, engine_factory, rank=0, world=1, sync=None, on_clip=None):
+    """Process this rank's share of `specs`.  Returns one record per processed clip:
+    dict(clip, rank, frames (propagated), objects, seconds, checksum).  `sync()` (e.g. torch.cuda.synchronize) brackets
+    the per-clip timer; `on_clip(spec, masks)` receives every result (mask egress)."""
+    parts = shard.assign_sequences([shard.clip_cost(s.frames - 1, s.objects) for s in specs], world)
+    records = []
+    for i in parts[rank]:
+        spec = specs[i]
+        core, first_mask = engine_factory(spec)
+        if sync:
+            sync()
+        t0 = time.perf_counter()
+        masks = core.interact(first_mask, 0)
+        if sync:
+            sync()
+        dt = time.perf_counter() - t0
+        if on_clip is not None:
+            on_clip(spec, masks)
+        records.append(dict(clip=spec.clip_id, rank=rank, frames=spec.frames - 1, objects=spec.objects,
+                            seconds=dt, checksum=mask_checksum(masks)))
+        del core
+    return records
+
+
+def summarize(all_records, n_specs=None):
+    """Aggregate of the gathered records of all ranks: every clip exactly once, total propagated frames, the busiest
+    rank's time (what bounds the wall clock of the sharded run) and the imbalance of the assignment."""
+    clips = sorted(r["clip"] for r in all_records)
+    if len(set(clips)) != len(clips) or (n_specs is not None and clips != list(range(n_specs))):
+        raise RuntimeError("suite sharding error: clips processed %d, unique %d, expected %s" % (len(clips), len(set(clips)), n_specs))
+    per_rank = {}
+    for r in all_records:
+        per_rank[r["rank"]] = per_rank.get(r["rank"], 0.0) + r["seconds"]
+    frames = sum(r["frames"] for r in all_records)
+    busiest = max(per_rank.values()) if per_rank else 0.0
+    return dict(clips=len(clips), frames=frames, busiest_rank_seconds=busiest,
+                mean_rank_seconds=sum(per_rank.values()) / max(1, len(per_rank)),
+                frames_per_second=frames / busiest if busiest > 0 else 0.0,
+                checksum=int(sum(r["checksum"] for r in all_records) & 0xFFFFFFFFFFFF))

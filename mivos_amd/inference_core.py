@@ -14,9 +14,9 @@ pad, k, t, h, w, nh, nw``), re-designed around the HIP engine:
   * fusion runs all K objects as one batch (one attention launch, one FusionNet chain);
   * the final argmax over all T frames is a single launch.
 """
-from collections import namedtuple
-
+import functools
 import os
+from collections import namedtuple
 
 import numpy as np
 import torch
@@ -58,6 +58,16 @@ def plan_pass(t, interacted, idx, forward, mem_freq, n_certain):
     return closest, total, steps
 
 
+def _on_core_device(fn):
+    """Public entry points run with the core's GPU as the current HIP device (the kernels launch on the current device's
+    stream), whatever device the caller had selected."""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class InferenceCore:
     """
     images       - unpadded, normalised CPU tensor [1,T,3,H,W]
@@ -72,9 +82,15 @@ class InferenceCore:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ops.MivosHipError("InferenceCore needs an MI355X device; mivos_amd has no CPU execution path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        # .to() of a network that already lives on the device keeps its compiled plan (packed weights); parameters
+        # mutated in place since the plan was built are detected once per clip
         self.prop_net = prop_net.to(self.device)
+        self.prop_net.refresh_plan_if_stale()
         if fuse_net is not None:
             self.fuse_net = fuse_net.to(self.device)
+            self.fuse_net.refresh_plan_if_stale()
         self.mem_profile, self.mem_freq = mem_profile, mem_freq
         self.data_dev = self.device if mem_profile == 0 else torch.device("cpu")
         self.result_dev = self.device if mem_profile in (0, 1) else torch.device("cpu")
@@ -95,6 +111,7 @@ class InferenceCore:
         self.prob[0] = 1e-7
 
         self.query_buf, self.image_buf = {}, {}
+        self._lookahead = set()                      # frames encoded ahead of their use (not yet consumed by a pass)
         self.interacted = set()
         self._certain_k = self._certain_v = None     # [K, n, h, w, C] rows per memory position
         self.propagated_frames = 0                   # do_pass iterations so far (the bench metric)
@@ -109,6 +126,7 @@ class InferenceCore:
         return None if self._certain_v is None else self._certain_v.permute(0, 4, 1, 2, 3)
 
     # ---- caches -----------------------------------------------------------------------------
+    @_on_core_device
     def get_image_buffered(self, idx):
         if self.data_dev == self.device:
             return self.images[:, idx]
@@ -129,7 +147,7 @@ class InferenceCore:
         q = self.query_buf.get(idx)
         if q is None:
             if len(self.query_buf) > self.q_buf_size:
-                self.query_buf = {}
+                self.query_buf, self._lookahead = {}, set()
             room = self.q_buf_size + 1 - len(self.query_buf)
             todo = [idx] + [t for t in upcoming if t != idx and t not in self.query_buf]
             todo = todo[:max(1, min(self.QUERY_BATCH, room))]
@@ -139,9 +157,21 @@ class InferenceCore:
                 frames = torch.cat([self.get_image_buffered(t) for t in todo], 0)
                 for t, qt in zip(todo, self.prop_net.encode_query_batch(frames)):
                     self.query_buf[t] = qt
+                self._lookahead.update(todo[1:])
                 q = self.query_buf[idx]
+        self._lookahead.discard(idx)
         return q
 
+    def drop_lookahead(self):
+        """Forget query features that were encoded ahead of their frame's turn (benchmark hygiene: a timed region that
+        starts here contains the encoding work of every frame it propagates).  Returns how many were dropped."""
+        n = len(self._lookahead)
+        for t in self._lookahead:
+            self.query_buf.pop(t, None)
+        self._lookahead = set()
+        return n
+
+    @_on_core_device
     def get_query_kv_buffered(self, idx):
         return self._query(idx).as_reference_tuple()
 
@@ -173,6 +203,7 @@ class InferenceCore:
                 step_cb()
         return closest
 
+    @_on_core_device
     def fuse_one_frame(self, tc, tr, ti, prev_mask, curr_mask, mk16, qk16):
         """Difference-aware fusion of the previous result with the new propagation for frame ti
         (reference inference_core.py:202-217), all K objects in one batch.  mk16: [K, h*w, 128] rows or
@@ -196,6 +227,7 @@ class InferenceCore:
         return ops.aggregate(w.view(K, 1, self.nh, self.nw), keep_bg=True)
 
     # ---- public entry points ------------------------------------------------------------------
+    @_on_core_device
     def interact(self, mask, idx, total_cb=None, step_cb=None):
         """mask: one-hot [K+1,1,H,W] (background first) of frame idx.  Propagates both ways from idx,
         fusing with earlier results between interacted frames.  Returns uint8 [T,H,W]."""
@@ -230,16 +262,29 @@ class InferenceCore:
         self.do_pass(rows, key_v, idx, False, step_cb=step_cb)
         return self._refresh_masks()
 
+    REFRESH_CHUNK_BYTES = 1 << 30     # host-resident results (mem_profile 2/3): probabilities visit the GPU in chunks
+
     def _refresh_masks(self):
-        """argmax over objects for every frame (one launch), crop the padding, copy to the host."""
-        prob = self.prob if self.prob.device == self.device else self.prob.to(self.device)
-        m = ops.argmax_u8(prob.view(self.k + 1, self.t * self.nh * self.nw)).view(self.t, 1, self.nh, self.nw)
-        self.masks = m.to(self.result_dev)
+        """argmax over objects for every frame, crop the padding, copy to the host.  Results resident in HBM: one launch
+        over all T frames.  Results on the host (mem_profile 2/3, the reference's low-memory profiles): bounded chunks of
+        frames are uploaded, so the GPU footprint stays O(chunk) like the reference's per-frame loop (:259-260)."""
         l, r, t, b = self.pad
-        out = m[:, 0, t:self.nh - b, l:self.nw - r]
-        self.np_masks = out.cpu().numpy().astype(np.uint8)
+        P = self.nh * self.nw
+        if self.prob.device == self.device:
+            m = ops.argmax_u8(self.prob.view(self.k + 1, self.t * P)).view(self.t, 1, self.nh, self.nw)
+            self.masks = m
+            self.np_masks = m[:, 0, t:self.nh - b, l:self.nw - r].cpu().numpy().astype(np.uint8)
+            return self.np_masks
+        step = max(1, self.REFRESH_CHUNK_BYTES // ((self.k + 1) * P * 4))
+        for t0 in range(0, self.t, step):
+            t1 = min(self.t, t0 + step)
+            chunk = self.prob[:, t0:t1].to(self.device).contiguous()
+            m = ops.argmax_u8(chunk.view(self.k + 1, (t1 - t0) * P)).view(t1 - t0, 1, self.nh, self.nw)
+            self.masks[t0:t1] = m.to(self.result_dev)
+        self.np_masks = self.masks[:, 0, t:self.nh - b, l:self.nw - r].cpu().numpy().astype(np.uint8)
         return self.np_masks
 
+    @_on_core_device
     def update_mask_only(self, prob_mask, idx):
         """Interaction without propagation (reference :273-293): prob_mask [K+1,1,nh,nw] (padded)."""
         prob_mask = prob_mask.to(self.device).float().contiguous()

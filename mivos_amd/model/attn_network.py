@@ -15,7 +15,13 @@ class AttentionMemory(nn.Module):
         self.k = k
 
     def forward(self, mk, qk):
-        raise MivosHipError("dense W is never materialised on the MI355X path; see AttentionReadNetwork.forward")
+        """attn_network.py:17-28: mk, qk [B,128,H,W] -> W [B, HW, HW] (softmax over the memory positions; every
+        sample has its own query map).  AttentionReadNetwork.forward itself uses the fused kernel and never builds W."""
+        B, CK, H, W = mk.shape
+        with ops.on_device(mk):
+            keys = mk.permute(0, 2, 3, 1).reshape(B, H * W, CK)
+            q = qk.permute(0, 2, 3, 1).reshape(B, H * W, CK)
+            return ops.attention_weights(keys, q)
 
 
 class AttentionReadNetwork(nn.Module):
@@ -31,8 +37,13 @@ class AttentionReadNetwork(nn.Module):
         self._plan = None
 
     def _apply(self, fn, *a, **k):
-        self._plan = None
-        return super()._apply(fn, *a, **k)
+        p = self.kv_q_f16.key_proj.weight
+        before = (p.device, p.dtype, p.data_ptr())
+        out = super()._apply(fn, *a, **k)
+        p = self.kv_q_f16.key_proj.weight
+        if (p.device, p.dtype, p.data_ptr()) != before:
+            self._plan = None
+        return out
 
     def load_state_dict(self, *a, **k):
         self._plan = None
@@ -62,9 +73,9 @@ class AttentionReadNetwork(nn.Module):
         b, _, h, w = mask11.shape
         nh, nw = h // 16, w // 16
         p = self.plan()
-        with torch.no_grad():
-            pos1, neg1 = (mask21 - mask11).clamp(0, 1), (mask11 - mask21).clamp(0, 1)
-            pos2, neg2 = (mask22 - mask12).clamp(0, 1), (mask12 - mask22).clamp(0, 1)
+        with torch.no_grad(), ops.on_device(image):
+            pos1, neg1 = ops.mask_diff(mask21, mask11)        # clamp(m21 - m11, 0, 1), clamp(m11 - m21, 0, 1)
+            pos2, neg2 = ops.mask_diff(mask22, mask12)
             k1 = self._mem_keys(image, mask21, mask22)
             k2 = self._mem_keys(image, mask22, mask21)
             P = h * w

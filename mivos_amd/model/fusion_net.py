@@ -21,8 +21,24 @@ class FusionNet(nn.Module):
         self._plan = None
 
     def _apply(self, fn, *a, **k):
+        p = self.final_conv.weight
+        before = (p.device, p.dtype, p.data_ptr())
+        out = super()._apply(fn, *a, **k)
+        p = self.final_conv.weight
+        if (p.device, p.dtype, p.data_ptr()) != before:       # a no-op .to(device) keeps the packed weights
+            self._plan = None
+        return out
+
+    def invalidate_plan(self):
+        """Call after mutating parameters in place; load_state_dict / device moves do it themselves."""
         self._plan = None
-        return super()._apply(fn, *a, **k)
+
+    def _param_versions(self):
+        return sum(p._version for p in self.parameters())
+
+    def refresh_plan_if_stale(self):
+        if self._plan is not None and self._plan_versions != self._param_versions():
+            self._plan = None
 
     def load_state_dict(self, *a, **k):
         self._plan = None
@@ -35,6 +51,7 @@ class FusionNet(nn.Module):
             with torch.no_grad():
                 self._plan = (self.conv1[0].pack(cin_pad=16), self.conv2[0].pack(), self.conv2[2].pack(),
                               self.conv3[0].pack(), self.conv3[2].pack(), self.final_conv.pack())
+                self._plan_versions = self._param_versions()
         return self._plan
 
     def run(self, x):
@@ -61,11 +78,12 @@ class FusionNet(nn.Module):
     def forward(self, im, seg1, seg2, attn, time):
         B, _, H, W = im.shape
         P = H * W
-        im, seg1, seg2, attn = (t.contiguous().float() for t in (im, seg1, seg2, attn))
-        outs = []
-        tl = time.detach().float().cpu().tolist()
-        for b in range(B):   # per-sample constant time planes (B == 1 on the inference path)
-            x = self.pack_inputs((im[b], 0), (seg1[b], 0), (seg2[b], 0), (attn[b], 0), tl[b], 1)
-            outs.append(self.run(x))
-        y = outs[0] if B == 1 else torch.cat(outs, 0)
-        return y.permute(0, 3, 1, 2)
+        with ops.on_device(im):
+            im, seg1, seg2, attn = (t.contiguous().float() for t in (im, seg1, seg2, attn))
+            outs = []
+            tl = time.detach().float().cpu().tolist()
+            for b in range(B):   # per-sample constant time planes (B == 1 on the inference path)
+                x = self.pack_inputs((im[b], 0), (seg1[b], 0), (seg2[b], 0), (attn[b], 0), tl[b], 1)
+                outs.append(self.run(x))
+            y = outs[0] if B == 1 else torch.cat(outs, 0)
+            return y.permute(0, 3, 1, 2)

@@ -52,21 +52,26 @@ class EvalMemoryReader(nn.Module):
         keys = mk.permute(0, 2, 3, 4, 1).reshape(B, T * H * W, CK)
         vals = mv.permute(0, 2, 3, 4, 1).reshape(B, T * H * W, CV)
         q = qk.permute(0, 2, 3, 1).reshape(H * W, CK).contiguous()
-        out = ops.memory_read(keys, vals, q, self.top_k)            # [B, HW, 512]
+        with ops.on_device(mk):
+            out = ops.memory_read(keys, vals, q, self.top_k)            # [B, HW, 512]
         return out.view(B, H, W, CV).permute(0, 3, 1, 2)
 
 
 class AttentionMemory(nn.Module):
     """prop_net.py:110-129.  The [HW x HW] softmax matrix is only materialised if somebody asks
-    for it through get_W(); get_attention() uses the fused kernel."""
+    for it (get_W); get_attention() uses the fused kernel that never writes it."""
 
     def __init__(self, k):
         super().__init__()
         self.k = k
 
     def forward(self, mk, qk):
-        raise MivosHipError("AttentionMemory.forward (dense W) is not on the MI355X path; use "
-                            "PropagationNetwork.get_attention, which fuses W into the pos/neg products")
+        """mk [B,128,T,H,W], qk [B or 1,128,H,W] -> W [B, T*H*W, H*W], softmax over the memory axis."""
+        B, _, T, H, W = mk.shape
+        with ops.on_device(mk):
+            keys = mk.permute(0, 2, 3, 4, 1).reshape(B, T * H * W, CK)
+            q = _nhwc(qk).reshape(qk.shape[0], H * W, CK)
+            return ops.attention_weights(keys, q[0] if qk.shape[0] == 1 else q)
 
 
 class QueryFeatures:
@@ -89,9 +94,16 @@ def _nhwc(t):
     return x if x.is_contiguous() else x.contiguous()
 
 
+MAX_TOP_K = 64      # csrc/memory_read.hip: candidate lists are sized for k <= 64 (the reference default is 50, the
+                    # DAVIS single-object configuration uses 20)
+
+
 class PropagationNetwork(nn.Module):
     def __init__(self, top_k=50):
         super().__init__()
+        if top_k is None or not (1 <= int(top_k) <= MAX_TOP_K):
+            raise MivosHipError(f"PropagationNetwork(top_k={top_k}): the MI355X memory-read kernel supports 1 <= top_k <= "
+                                f"{MAX_TOP_K} (reference default 50); top_k=None (full softmax over the bank) is not implemented")
         self.mask_rgb_encoder = MaskRGBEncoder()
         self.rgb_encoder = RGBEncoder()
         self.kv_m_f16 = KeyValue(1024, keydim=CK, valdim=CV)
@@ -103,12 +115,33 @@ class PropagationNetwork(nn.Module):
 
     # ---- compiled-plan management -------------------------------------------------------
     def _apply(self, fn, *a, **k):
-        self._plan = None
-        return super()._apply(fn, *a, **k)
+        # .to()/.cuda() of an already placed network keeps every parameter's storage: keep the compiled plan then
+        # (InferenceCore re-applies .to(device) for every clip; re-packing ~120 layers each time would be wasted work)
+        before = self._storage_key()
+        out = super()._apply(fn, *a, **k)
+        if self._storage_key() != before:
+            self._plan = None
+        return out
+
+    def _storage_key(self):
+        p = self.kv_q_f16.key_proj.weight
+        return (p.device, p.dtype, p.data_ptr())
+
+    def _param_versions(self):
+        return sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
 
     def load_state_dict(self, *a, **k):
         self._plan = None
         return super().load_state_dict(*a, **k)
+
+    def invalidate_plan(self):
+        """Call after mutating parameters in place (``p.data.copy_``, optimiser steps) so that the packed weights are
+        rebuilt; ``load_state_dict`` / device moves do it themselves, and InferenceCore checks once per clip."""
+        self._plan = None
+
+    def refresh_plan_if_stale(self):
+        if self._plan is not None and self._plan["versions"] != self._param_versions():
+            self._plan = None
 
     def plan(self):
         if self._plan is None:
@@ -119,7 +152,7 @@ class PropagationNetwork(nn.Module):
             with torch.no_grad():
                 self._plan = dict(menc=self.mask_rgb_encoder.compile(), qenc=self.rgb_encoder.compile(),
                                   kv_m=self.kv_m_f16.compile(), kv_q=self.kv_q_f16.compile(),
-                                  dec=self.decoder.compile())
+                                  dec=self.decoder.compile(), versions=self._param_versions())
         return self._plan
 
     # ---- internal fast path (NHWC) ------------------------------------------------------
@@ -141,6 +174,9 @@ class PropagationNetwork(nn.Module):
         branches for the whole batch."""
         p = self.plan()
         B, _, H, W = frames.shape
+        cap = ops.max_act_batch(H // 4, W // 4, 256)          # 32-bit offsets of the LDS-DMA kernels (ops.ACT_BYTES_LIMIT)
+        if B > cap:
+            return [q for i in range(0, B, cap) for q in self.encode_query_batch(frames[i:i + cap], with_skip)]
         frames = frames.contiguous()
         P = H * W
         flat = frames.reshape(-1)
@@ -174,6 +210,19 @@ class PropagationNetwork(nn.Module):
         frame, masks = frame.contiguous(), masks.contiguous().float()
         others = ops.mask_others(masks) if K > 1 else torch.zeros_like(masks)
         P = H * W
+        cap = ops.max_act_batch(H // 4, W // 4, 256)
+        if K > cap:                                             # object batch in chunks (tensors stay < 2 GB)
+            if key_out is None:
+                key_out = torch.empty((K, H // 16, W // 16, CK), dtype=torch.float32, device=frame.device)
+                val_out = torch.empty((K, H // 16, W // 16, CV), dtype=torch.float32, device=frame.device)
+            for i in range(0, K, cap):
+                self._memorize_chunk(p, frame, masks[i:i + cap], others[i:i + cap], key_out[i:i + cap], val_out[i:i + cap])
+            return key_out, val_out
+        return self._memorize_chunk(p, frame, masks, others, key_out, val_out)
+
+    def _memorize_chunk(self, p, frame, masks, others, key_out, val_out):
+        K, _, H, W = masks.shape
+        P = H * W
         planes = [(frame[0, c], 0) for c in range(3)] + [(masks, P), (others, P)]
         x = ops.interleave(planes, K, P, 8, frame.device).view(K, H, W, 8)
         f16, _, _ = run_trunk(p["menc"], x, keep=False)
@@ -185,6 +234,9 @@ class PropagationNetwork(nn.Module):
         dec = self.plan()["dec"]
         K = keys.shape[0]
         _, h, w, _ = q.f16.shape
+        cap = ops.max_act_batch(4 * h, 4 * w, 256)
+        if K > cap:
+            return torch.cat([self.segment(keys[i:i + cap], values[i:i + cap], q, logits) for i in range(0, K, cap)], 0)
         s8, s4 = self._skip(q)
         m4 = torch.empty((K, h, w, 2 * CV), dtype=torch.float32, device=keys.device)
         ops.memory_read(keys, values, q.k16.view(h * w, CK), self.memory.top_k, out=m4.view(K, h * w, 2 * CV)[:, :, :CV])
@@ -201,37 +253,44 @@ class PropagationNetwork(nn.Module):
         return ops.attention_align(mk, qk16, pos16, neg16)
 
     # ---- reference-compatible public API (logical NCHW) -----------------------------------
+    # Every public method makes the device of its operands current for the duration of the call (the kernels launch
+    # on the current HIP device's stream).
     def memorize(self, frame, masks):
         k, _, h, w = masks.shape
-        k16, v16 = self.memorize_into(frame.view(1, 3, h, w), masks)
-        return k16.permute(0, 3, 1, 2).unsqueeze(2), v16.permute(0, 3, 1, 2).unsqueeze(2)
+        with ops.on_device(masks):
+            k16, v16 = self.memorize_into(frame.view(1, 3, h, w), masks)
+            return k16.permute(0, 3, 1, 2).unsqueeze(2), v16.permute(0, 3, 1, 2).unsqueeze(2)
 
     def get_query_values(self, frame):
-        return self.encode_query(frame).as_reference_tuple()
+        with ops.on_device(frame):
+            return self.encode_query(frame).as_reference_tuple()
 
     def segment_with_query(self, keys, values, f16, f8, f4, k16, v16):
         K, _, T, h, w = keys.shape
-        feats = [_nhwc(t) for t in (f16, f8, f4)]
-        if ops.act_path():
-            feats = [ops.to_act(t) for t in feats]
-        q = QueryFeatures(*feats, _nhwc(k16), _nhwc(v16))
-        kr = keys.permute(0, 2, 3, 4, 1).reshape(K, T * h * w, CK)
-        vr = values.permute(0, 2, 3, 4, 1).reshape(K, T * h * w, CV)
-        prob = self.segment(kr, vr, q)
-        return prob.unsqueeze(1)
+        with ops.on_device(keys):
+            feats = [_nhwc(t) for t in (f16, f8, f4)]
+            if ops.act_path():
+                feats = [ops.to_act(t) for t in feats]
+            q = QueryFeatures(*feats, _nhwc(k16), _nhwc(v16))
+            kr = keys.permute(0, 2, 3, 4, 1).reshape(K, T * h * w, CK)
+            vr = values.permute(0, 2, 3, 4, 1).reshape(K, T * h * w, CV)
+            prob = self.segment(kr, vr, q)
+            return prob.unsqueeze(1)
 
     def get_W(self, mk16, qk):
+        """prop_net.py:183-185: the dense [HW x HW] attention matrix (softmax over the memory positions)."""
         return self.attn_memory(mk16, qk)
 
     def get_attention(self, mk16, pos_mask, neg_mask, qk16):
         b, _, h, w = pos_mask.shape
         nh, nw = h // 16, w // 16
-        mk = mk16.permute(0, 2, 3, 4, 1).reshape(b, nh * nw, CK)
-        qk = _nhwc(qk16).reshape(nh * nw, CK)
-        pos = ops.area_pool16(pos_mask.reshape(b, h, w)).view(b, nh * nw)
-        neg = ops.area_pool16(neg_mask.reshape(b, h, w)).view(b, nh * nw)
-        low = self.attention_lowres(mk, pos, neg, qk)                   # [b, 2, nh*nw]
-        return ops.resize_bilinear(low.view(b * 2, nh, nw), h, w).view(b, 2, h, w)
+        with ops.on_device(mk16):
+            mk = mk16.permute(0, 2, 3, 4, 1).reshape(b, nh * nw, CK)
+            qk = _nhwc(qk16).reshape(nh * nw, CK)
+            pos = ops.area_pool16(pos_mask.reshape(b, h, w)).view(b, nh * nw)
+            neg = ops.area_pool16(neg_mask.reshape(b, h, w)).view(b, nh * nw)
+            low = self.attention_lowres(mk, pos, neg, qk)                   # [b, 2, nh*nw]
+            return ops.resize_bilinear(low.view(b * 2, nh, nw), h, w).view(b, 2, h, w)
 
     def forward(self, *a, **k):
         raise NotImplementedError("use memorize / get_query_values / segment_with_query / get_attention")

@@ -23,16 +23,39 @@ PROFILE = None
 
 
 def _ensure_device(t):
+    """Every entry point passes its first operand through here: the tensor must live on the CURRENT HIP device (kernels
+    launch on the current device's stream; a tensor of another GPU would be touched from the wrong device, unordered with
+    its own stream), and that device must be a gfx950."""
     if not t.is_cuda:
         raise MivosHipError("mivos_amd runs on MI355X (gfx950) only and has no CPU fallback; got a CPU tensor")
     idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    if idx != torch.cuda.current_device():
+        raise MivosHipError(f"tensor lives on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}: wrap the "
+                            f"call in `with ops.on_device(tensor)` (InferenceCore and the network classes do)")
     if idx not in _checked_devices:
         check(_lib.load().mivos_device_check(idx))
         _checked_devices.add(idx)
 
 
+def on_device(t):
+    """Context manager making the device of tensor / torch.device `t` current (no-op when it already is)."""
+    dev = t.device if isinstance(t, (torch.Tensor, Act)) else torch.device(t)
+    if dev.type != "cuda":
+        raise MivosHipError("mivos_amd runs on MI355X (gfx950) only and has no CPU fallback; got a CPU tensor / device")
+    return torch.cuda.device(dev)
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+# LDS-DMA convolutions address their (zero-bordered) input with 32-bit buffer offsets: one tensor < 2 GB
+ACT_BYTES_LIMIT = 0x7ff00000
+
+
+def max_act_batch(h, w, c):
+    """How many [h, w, c] images fit one SH32 activation tensor (>= 1; callers chunk their batch to this)."""
+    return max(1, ACT_BYTES_LIMIT // ((h + 2) * (w + 2) * c * 4))
 
 
 def _f32(t):
@@ -321,8 +344,8 @@ def upsample2x_add(skip, up):
 _ws_cache = {}
 
 
-def _workspace(nbytes, device):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+def _workspace(nbytes, device, purpose="splitk"):
+    key = (purpose, device.index, torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -354,9 +377,23 @@ def memory_read(keys, values, qk, top_k, out=None):
     assert out.shape == (k, n_q, 512) and out.stride(2) == 1
     lib = _lib.load()
     nbytes = lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k)
-    ws = _workspace(nbytes, keys.device)
-    check(lib.mivos_memory_read_topk(keys.data_ptr(), ko, values.data_ptr(), vo, qk.data_ptr(), out.data_ptr(),
-                                     out.stride(0), out.stride(1), k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
+    ws = _workspace(nbytes, keys.device, "memread")
+    if PROFILE is None:
+        check(lib.mivos_memory_read_topk(keys.data_ptr(), ko, values.data_ptr(), vo, qk.data_ptr(), out.data_ptr(),
+                                         out.stride(0), out.stride(1), k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
+        return out
+    # profiling (bench.py): the two launches one by one with HIP events on the launch stream around each
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record()
+    check(lib.mivos_memory_read_select(keys.data_ptr(), ko, qk.data_ptr(), k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
+    ev[1].record()
+    ev[2].record()
+    check(lib.mivos_memory_read_finalize(values.data_ptr(), vo, out.data_ptr(), out.stride(0), out.stride(1), k, n_mem, n_q, top_k,
+                                         ws.data_ptr(), ws.numel(), _stream()))
+    ev[3].record()
+    # affinity: 2*K*n_mem*n_q*128 FLOP, keys + queries read once; finalize: k value rows of 2 KB per (object, query) + the output
+    PROFILE.append((90, 2.0 * k * n_mem * n_q * 128, ev[0], ev[1], (k, n_mem, n_q, top_k, 4.0 * 128 * (k * n_mem + n_q))))
+    PROFILE.append((91, 2.0 * k * n_q * top_k * 512, ev[2], ev[3], (k, n_mem, n_q, top_k, 4.0 * 512 * k * n_q * (top_k + 1))))
     return out
 
 
@@ -369,7 +406,7 @@ def memory_read_indices(keys, qk, top_k):
     idx = torch.empty((k, n_q, top_k), dtype=torch.int32, device=keys.device)
     wgt = torch.empty((k, n_q, top_k), dtype=torch.float32, device=keys.device)
     lib = _lib.load()
-    ws = _workspace(lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k), keys.device)
+    ws = _workspace(lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k), keys.device, "memread")
     check(lib.mivos_memory_read_topk_indices(keys.data_ptr(), ko, qk.contiguous().data_ptr(), idx.data_ptr(), wgt.data_ptr(),
                                              k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
     return idx, wgt
@@ -383,6 +420,19 @@ def attention_align(mk, qk, pos16, neg16):
     out = torch.empty((k, 2, n_pos), dtype=torch.float32, device=mk.device)
     check(_lib.load().mivos_attention_align(mk.data_ptr(), qk.data_ptr(), pos16.data_ptr(), neg16.data_ptr(), out.data_ptr(), k, n_pos, _stream()))
     return out
+
+
+def attention_weights(mk, qk):
+    """mk [B, n_mem, 128], qk [n_q, 128] (shared) or [B, n_q, 128] -> dense W [B, n_mem, n_q] = softmax over n_mem
+    (AttentionMemory.forward; prop_net.py:115-129)."""
+    _ensure_device(mk)
+    mk, qk = _f32(mk).contiguous(), _f32(qk).contiguous()
+    b, n_mem, _ = mk.shape
+    n_q = qk.shape[-2]
+    qs = 0 if qk.dim() == 2 else n_q * 128
+    w = torch.empty((b, n_mem, n_q), dtype=torch.float32, device=mk.device)
+    check(_lib.load().mivos_attention_weights(mk.data_ptr(), qk.data_ptr(), qs, w.data_ptr(), b, n_mem, n_q, _stream()))
+    return w
 
 
 def area_pool16(x):
@@ -417,6 +467,17 @@ def aggregate(prob, keep_bg=False, hard=False, soft_bg=True):
     fn = _lib.load().mivos_aggregate_wbg if soft_bg else _lib.load().mivos_aggregate_sbg
     check(fn(prob.data_ptr(), out.data_ptr(), k, p, int(keep_bg), int(hard), _stream()))
     return out
+
+
+def aggregate_channel(prob, keep_bg=False, hard=False):
+    """prob [B, K, H, W] -> (logits [B, K+1, H, W], softmax [B, K(+1), H, W]); aggregate.py:39-53."""
+    _ensure_device(prob)
+    prob = _f32(prob).contiguous()
+    b, k, h, w = prob.shape
+    logits = torch.empty((b, k + 1, h, w), dtype=torch.float32, device=prob.device)
+    soft = torch.empty((b, k + 1 if keep_bg else k, h, w), dtype=torch.float32, device=prob.device)
+    check(_lib.load().mivos_aggregate_wbg_channel(prob.data_ptr(), logits.data_ptr(), soft.data_ptr(), b, k, h * w, int(keep_bg), int(hard), _stream()))
+    return logits, soft
 
 
 def argmax_u8(prob, out=None):

@@ -213,3 +213,40 @@ def synthetic_clip(t, h, w, k, seed=0):
         for j in range(k + 1):
             masks[i, j, 0] = label == j
     return images, torch.from_numpy(masks)
+
+
+def synthetic_clip_device(t, h, w, k, seed=0, device="cuda", chunk=64):
+    """Same recipe as ``synthetic_clip`` evaluated with torch ops on `device` (benchmark input generation for long /
+    large clips: 1000 frames of 1080p are 25 GB, which the numpy version builds in minutes).  Frames agree with the
+    numpy version up to the bicubic filter's rounding, the masks exactly; the clips used for parity checks always come
+    from ``synthetic_clip``.  Returns images [1,T,3,h,w] f32 and one-hot masks [T,K+1,1,h,w] f32 on `device`."""
+    dev = torch.device(device)
+    r = np.random.RandomState(1234 + seed)
+    base = torch.from_numpy(r.standard_normal((3, h // 8 + 2, w // 8 + 2)).astype(np.float32)).to(dev)
+    drift = torch.from_numpy(r.standard_normal((3, h // 8 + 2, w // 8 + 2)).astype(np.float32)).to(dev)
+    mean = torch.tensor([0.485, 0.456, 0.406], device=dev)[None, :, None, None]
+    std = torch.tensor([0.229, 0.224, 0.225], device=dev)[None, :, None, None]
+    images = torch.empty((1, t, 3, h, w), dtype=torch.float32, device=dev)
+    a_all = torch.arange(t, device=dev, dtype=torch.float32) / max(t - 1, 1)
+    for t0 in range(0, t, chunk):
+        a = a_all[t0:t0 + chunk][:, None, None, None]
+        lo = (1 - a) * base[None] + a * drift[None]
+        img = F.interpolate(lo, size=(h, w), mode="bicubic", align_corners=False)
+        img = torch.round((0.5 + 0.22 * img).clamp(0, 1) * 255) / 255
+        images[0, t0:t0 + chunk] = (img - mean) / std
+    cy0 = r.uniform(0.3, 0.7, k) * h
+    cx0 = (np.arange(k) + 0.5) / k * w
+    vy, vx = r.uniform(-0.15, 0.15, k) * h, r.uniform(-0.08, 0.08, k) * w
+    ry, rx = r.uniform(0.12, 0.25, k) * h, np.full(k, 0.35 / k * w)
+    yy = torch.arange(h, device=dev, dtype=torch.float32)[:, None]
+    xx = torch.arange(w, device=dev, dtype=torch.float32)[None, :]
+    masks = torch.zeros((t, k + 1, 1, h, w), dtype=torch.float32, device=dev)
+    for i in range(t):
+        a = i / max(t - 1, 1)
+        label = torch.zeros((h, w), dtype=torch.int64, device=dev)
+        for j in range(k):
+            inside = ((yy - np.float32(cy0[j] + a * vy[j])) / np.float32(ry[j])) ** 2 + ((xx - np.float32(cx0[j] + a * vx[j])) / np.float32(rx[j])) ** 2 < 1
+            label = torch.where(inside & (label == 0), torch.full_like(label, j + 1), label)
+        for j in range(k + 1):
+            masks[i, j, 0] = (label == j).float()
+    return images, masks

@@ -32,7 +32,48 @@ def _np(x):
     return x.detach().cpu().numpy()
 
 
+def make_attn_golden():
+    """attn_small.npz: the reference's AttentionReadNetwork (model/attn_network.py:30-80, the training-time twin of
+    get_attention) and aggregate_wbg_channel (model/aggregate.py:39-53) on seeded inputs."""
+    torch.set_grad_enabled(False)
+    ref = __import__("oracle.ref_loader", fromlist=["load_reference"]).load_reference()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ref["attn_network"].AttentionReadNetwork().eval()
+    sd = Wt.make_prop_state(0)
+    missing = net.load_state_dict({k: v for k, v in sd.items() if not k.startswith("decoder.")}, strict=True)
+    r = np.random.RandomState(11)
+    b, h, w = 2, 64, 96
+    image = torch.from_numpy(r.standard_normal((b, 3, h, w)).astype(np.float32))
+    query = torch.from_numpy(r.standard_normal((b, 3, h, w)).astype(np.float32))
+    m = [torch.from_numpy((r.rand(b, 1, h, w) > thr).astype(np.float32)) for thr in (0.5, 0.6, 0.7, 0.55)]
+    a1, a2 = net(image, m[0], m[1], m[2], m[3], query)
+    out = dict(an_image=_np(image), an_query=_np(query), an_m11=_np(m[0]), an_m21=_np(m[1]), an_m12=_np(m[2]), an_m22=_np(m[3]),
+               an_out1=_np(a1), an_out2=_np(a2))
+    o1, o2 = O.attention_read_network(sd, image, m[0], m[1], m[2], m[3], query)
+    print("attn_network |oracle-ref|", float((o1 - a1).abs().max()), float((o2 - a2).abs().max()))
+    # dense W of AttentionMemory (attn_network.py:17-28) on small random keys
+    mk, qk = torch.from_numpy(r.standard_normal((2, 128, 4, 6)).astype(np.float32)), torch.from_numpy(r.standard_normal((2, 128, 4, 6)).astype(np.float32))
+    W = net.memory(mk, qk)
+    out.update(aw_mk=_np(mk), aw_qk=_np(qk), aw_out=_np(W))
+    print("dense W      |oracle-ref|", float((O.attention_weights(mk, qk) - W).abs().max()))
+    # aggregate_wbg_channel
+    p = torch.from_numpy(r.rand(2, 3, 16, 20).astype(np.float32))
+    p[:, :, :2] = 0.0
+    p[:, :, 2:4] = 1.0
+    for hard in (False, True):
+        lg, sm = ref["aggregate"].aggregate_wbg_channel(p, keep_bg=True, hard=hard)
+        out.update({f"ac_logits_{int(hard)}": _np(lg), f"ac_soft_{int(hard)}": _np(sm)})
+        olg, osm = O.aggregate_wbg_channel(p, keep_bg=True, hard=hard)
+        print("aggregate_ch |oracle-ref|", float((olg - lg).abs().max()), float((osm - sm).abs().max()))
+    out["ac_in"] = _np(p)
+    np.savez_compressed(os.path.join(G, "attn_small.npz"), **out)
+    print("attn_small.npz", os.path.getsize(os.path.join(G, "attn_small.npz")) // 1024, "KiB")
+
+
 def main():
+    if "--attn-only" in sys.argv:
+        return make_attn_golden()
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
     os.makedirs(G, exist_ok=True)
@@ -156,6 +197,7 @@ def main():
     print("trace equal:", trace == ocore.trace)
     print(" ".join(trace))
     np.savez_compressed(os.path.join(G, "e2e_small.npz"), **e2e)
+    make_attn_golden()
     for f in sorted(os.listdir(G)):
         print(f, os.path.getsize(os.path.join(G, f)) // 1024, "KiB")
 

@@ -183,6 +183,44 @@ def get_attention(mk16, pos_mask, neg_mask, qk16):
     a = torch.cat([pos, neg], 1).reshape(b, 2, nh, nw)
     return F.interpolate(a, mode="bilinear", size=(h, w), align_corners=False)
 
+def attention_weights(mk, qk):
+    """AttentionMemory.forward of model/attn_network.py:17-28: mk, qk [B,CK,H,W] -> W [B,HW,HW], softmax over the
+    memory positions (dim 1); every sample has its own query map."""
+    B, CK = mk.shape[:2]
+    mi = mk.reshape(B, CK, -1).transpose(1, 2)
+    qi = qk.reshape(B, CK, -1) / math.sqrt(CK)
+    return F.softmax(torch.bmm(mi, qi), dim=1)
+
+
+def attention_read_network(sd, image, mask11, mask21, mask12, mask22, query_image):
+    """AttentionReadNetwork.forward, model/attn_network.py:46-80 (same encoders / KeyValue weights as the propagation
+    network): aligned positive / negative difference maps of two objects."""
+    b, _, h, w = mask11.shape
+    nh, nw = h // 16, w // 16
+    pos1, neg1 = (mask21 - mask11).clamp(0, 1), (mask11 - mask21).clamp(0, 1)
+    pos2, neg2 = (mask22 - mask12).clamp(0, 1), (mask12 - mask22).clamp(0, 1)
+    k1, _ = key_value(sd, "kv_m_f16.", mask_rgb_encoder(sd, image, mask21, mask22))
+    k2, _ = key_value(sd, "kv_m_f16.", mask_rgb_encoder(sd, image, mask22, mask21))
+    qk16, _ = key_value(sd, "kv_q_f16.", rgb_encoder(sd, query_image)[0])
+    outs = []
+    for keys, pos, neg in ((k1, pos1, neg1), (k2, pos2, neg2)):
+        W = attention_weights(keys, qk16)
+        pm = F.interpolate(pos, size=(nh, nw), mode="area").view(b, 1, nh * nw) @ W
+        nm = F.interpolate(neg, size=(nh, nw), mode="area").view(b, 1, nh * nw) @ W
+        a = torch.cat([pm, nm], 1).reshape(b, 2, nh, nw)
+        outs.append(F.interpolate(a, mode="bilinear", size=(h, w), align_corners=False))
+    return outs[0], outs[1]
+
+
+def aggregate_wbg_channel(prob, keep_bg=False, hard=False):
+    """model/aggregate.py:39-53: prob [B,K,H,W] -> (logits [B,K+1,H,W], softmax over dim 1)."""
+    p = torch.cat([torch.prod(1 - prob, dim=1, keepdim=True), prob], 1).clamp(1e-7, 1 - 1e-7)
+    logits = torch.log(p / (1 - p))
+    if hard:
+        logits = logits * 1000
+    s = F.softmax(logits, dim=1)
+    return logits, (s if keep_bg else s[:, 1:])
+
 # ------------------------------------------------------------------ network methods
 
 

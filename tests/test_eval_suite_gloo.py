@@ -1,0 +1,86 @@
+"""Suite runner (mivos_amd/eval_suite.py) on CPU: synthetic config-4 suite, world_size-2 gloo run with a stub engine —
+every clip is processed exactly once, the aggregate equals the single-process run."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from mivos_amd import eval_suite as ES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+STUB = textwrap.dedent("""
+    import numpy as np
+
+    class StubCore:
+        '''Deterministic stand-in for InferenceCore: "propagates" by rolling the first mask.'''
+        def __init__(self, spec):
+            self.spec = spec
+        def interact(self, mask, idx):
+            s = self.spec
+            out = np.stack([np.roll(mask, t, axis=1) for t in range(s.frames)], 0).astype(np.uint8)
+            return out
+
+    def factory(spec):
+        r = np.random.RandomState(spec.seed)
+        first = (r.rand(12, 20) * (spec.objects + 1)).astype(np.uint8)
+        return StubCore(spec), first
+""")
+
+
+def test_suite_spec_and_resize_rule():
+    assert ES.yv_480p_size(720, 1280) == (480, 853)        # yv_test_dataset.py:102-109: landscape
+    assert ES.yv_480p_size(1280, 720) == (853, 480)        # portrait: h*480//w
+    assert ES.yv_480p_size(480, 854) == (480, 854)
+    specs = ES.synthetic_suite(474)
+    assert len(specs) == 474 and specs == ES.synthetic_suite(474)
+    assert all(s.frames % 5 == 0 and 20 <= s.frames <= 180 and 1 <= s.objects <= 5 for s in specs)
+    assert {s.objects for s in specs} == {1, 2, 3, 4, 5} and (specs[0].height, specs[0].width) == (480, 853)
+
+
+def test_single_process_suite_and_summary():
+    ns = {}
+    exec(STUB, ns)
+    specs = ES.synthetic_suite(9)
+    seen = []
+    recs = ES.run_suite(specs, ns["factory"], on_clip=lambda s, m: seen.append((s.clip_id, m.shape[0])))
+    assert sorted(c for c, _ in seen) == list(range(9)) and all(t == specs[c].frames for c, t in seen)
+    s = ES.summarize(recs, 9)
+    assert s["clips"] == 9 and s["frames"] == sum(sp.frames - 1 for sp in specs)
+    dup = recs + recs[:1]
+    try:
+        ES.summarize(dup, 9)
+        raise AssertionError("duplicate clip not detected")
+    except RuntimeError:
+        pass
+
+
+def test_two_rank_gloo_suite(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        from mivos_amd import shard, eval_suite as ES
+    """) + STUB + textwrap.dedent("""
+        rank, world, local = shard.init_distributed(backend="gloo")
+        specs = ES.synthetic_suite(23)
+        recs = ES.run_suite(specs, factory, rank, world)
+        shard.barrier()
+        allrecs = shard.gather_records(recs)
+        if rank == 0:
+            s = ES.summarize(allrecs, 23)
+            ref = ES.summarize(ES.run_suite(specs, factory), 23)
+            assert s["checksum"] == ref["checksum"] and s["frames"] == ref["frames"], (s, ref)
+            loads = {}
+            for r in allrecs:
+                loads[r["rank"]] = loads.get(r["rank"], 0) + shard.clip_cost(r["frames"], r["objects"])
+            assert set(loads) == {0, 1} and max(loads.values()) <= 1.2 * min(loads.values()), loads
+            print("SUITE_OK", s["clips"], s["frames"])
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert "SUITE_OK 23" in out.stdout, out.stdout + out.stderr

@@ -288,6 +288,10 @@ def test_aggregate_argmax_diff_others(golden_dir):
     assert float((ops.aggregate(pd, keep_bg=True, soft_bg=False).cpu() - sbg).abs().max()) < 2e-6
     assert float((ops.aggregate(pd, keep_bg=False).cpu() - soft[1:]).abs().max()) < 2e-6
     g = torch.Generator().manual_seed(3)
+    many = torch.rand(40, 1, 16, 24, generator=g) * 0.2       # more objects than the register-cached variant holds (32)
+    for hard in (False, True):
+        got = ops.aggregate(many.to(DEV), keep_bg=True, hard=hard).cpu()
+        assert got.shape == (41, 1, 16, 24) and float((got - O.aggregate_wbg(many, True, hard=hard)).abs().max()) < 2e-6
     prob = torch.rand(4, 7, 1, 16, 24, generator=g)
     prob[2, 3] = prob[1, 3]                                   # ties: first index must win
     got = ops.argmax_u8(prob.to(DEV).view(4, -1)).cpu().view(7, 1, 16, 24)
@@ -336,7 +340,10 @@ def test_memory_read_golden(golden_dir):
     assert float((got - ref).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("T,h,w,K,top_k", [(1, 8, 10, 1, 50), (3, 9, 13, 2, 50), (5, 30, 54, 1, 20), (5, 30, 54, 3, 50), (23, 30, 54, 1, 50)])
+@pytest.mark.parametrize("T,h,w,K,top_k", [(1, 8, 10, 1, 50), (3, 9, 13, 2, 50), (5, 30, 54, 1, 20), (5, 30, 54, 3, 50), (23, 30, 54, 1, 50),
+                                           (40, 8, 10, 1, 50),      # one 64-query stream cut into many segments (10 lists to merge)
+                                           (7, 30, 54, 5, 50),      # the benchmark's shape: runs that cross stream boundaries
+                                           (2, 68, 120, 1, 64)])    # 1080p grid, largest supported k
 def test_memory_read_vs_oracle(T, h, w, K, top_k):
     mk, mv, qk = _mem_case(T, h, w, K, seed=T * 100 + K)
     got, idx, wgt = _run_mem(mk, mv, qk, top_k)

@@ -103,3 +103,17 @@ def test_end_to_end_inference_core(golden_dir, synthetic_states):
         assert (out != g[f"masks_{n}"]).mean() <= 1e-4
         assert float((core.prob - T(g[f"prob_{n}"])).abs().max()) <= 1e-4
     assert " ".join(core.trace) == str(g["trace"])
+
+
+def test_attention_read_network_and_channel_aggregate(golden_dir, synthetic_states):
+    """attn_small.npz: the reference's AttentionReadNetwork / AttentionMemory (model/attn_network.py) and
+    aggregate_wbg_channel (model/aggregate.py:39-53)."""
+    with np.load(os.path.join(golden_dir, "attn_small.npz")) as z:
+        g = {k: T(z[k]) for k in z.files}
+    o1, o2 = O.attention_read_network(synthetic_states[0], g["an_image"], g["an_m11"], g["an_m21"], g["an_m12"], g["an_m22"], g["an_query"])
+    assert float((o1 - g["an_out1"]).abs().max()) <= TOL and float((o2 - g["an_out2"]).abs().max()) <= TOL
+    assert float((O.attention_weights(g["aw_mk"], g["aw_qk"]) - g["aw_out"]).abs().max()) <= TOL
+    for hard in (0, 1):
+        lg, sm = O.aggregate_wbg_channel(g["ac_in"], keep_bg=True, hard=bool(hard))
+        assert float((lg - g[f"ac_logits_{hard}"]).abs().max()) <= TOL * 1000 ** hard
+        assert float((sm - g[f"ac_soft_{hard}"]).abs().max()) <= TOL
