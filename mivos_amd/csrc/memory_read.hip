@@ -35,8 +35,12 @@ constexpr int QW = 16;      // queries per wave (MFMA N)
 constexpr int QT = 64;      // queries per workgroup
 constexpr int KT = 32;      // memory positions per LDS tile (two 16-row MFMA sub-tiles)
 constexpr int KLD = 132;    // LDS pitch of a key row (floats)
-constexpr int CAP = 240;    // candidate slots per query (LDS)
-constexpr int CAP_TRIGGER = CAP - KT;   // a tile adds at most 32 candidates per query
+constexpr int REG = 61;                 // lane (q, g) appends to ITS region of REG entries: private fill level in a VGPR, no
+                                        // atomics.  Regions are laid out [wave][g][q][REG]: the 16 lanes of a ds_write_b64 lane
+                                        // group (same g, q = 0..15) are REG entries = 122 dwords apart, and with REG odd that
+                                        // walks all 32 bank pairs (REG = 60, or the query-major order, gave 8-way conflicts)
+constexpr int CAP = 4 * REG;            // candidate slots per query
+constexpr int REG_TRIGGER = REG - 1 - 8;   // a tile adds at most 8 candidates per lane (one slot of the 61 is padding)
 constexpr int SLACK = 16;   // a compaction leaves between k and k + SLACK survivors
 constexpr int MAX_TOPK = 64;
 constexpr int MAX_SLOTS = 12;                        // candidate lists (segments) per stream
@@ -58,50 +62,109 @@ __device__ __forceinline__ uint64_t pack_cand(float s, uint32_t idx) {
 __device__ __forceinline__ float cand_score(uint64_t c) { return ord2f((uint32_t)(c >> 32)); }
 __device__ __forceinline__ uint32_t cand_index(uint64_t c) { return 0xffffffffu - (uint32_t)c; }
 
+// max over the 64 lanes (wave-uniform): rotate-and-max butterfly inside the four 16-lane rows (DPP row_ror, no LDS),
+// then the four row results through SGPRs.
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));   // row_ror:8
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));   // row_ror:4
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false));   // row_ror:2
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false));   // row_ror:1
+  const uint32_t a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+
 // Largest 64-bit prefix p with #(e >= p) >= k, found MSB first; stops early once k <= #(e >= p) <= k + slack.
-// N entries per lane, empty entries are 0.  Wave-uniform result; `count` = #(e >= p).
+// N entries per lane, empty entries are 0; at least k entries are valid.  Wave-uniform result; `count` = #(e >= p).
+// The bits every valid entry shares (sign, exponent, ... of scores in a narrow band) are skipped, and the search runs on the
+// 32-bit score words alone (single-rate compares) until the cut is found; only exact score ties straddling the cut make it
+// continue into the index words.
 template <int N>
 __device__ __forceinline__ uint64_t bisect_kth(const uint64_t (&e)[N], int k, int slack, int &count) {
-  uint64_t prefix = 0;
-  int c_at = 0;
-#pragma unroll 1
-  for (int b = 63; b >= 0; --b) {
-    const uint64_t trial = prefix | (1ull << b);
-    int c = 0;
+  uint32_t h[N];
+  uint32_t mx = 0u, nmn = 0u;                        // max of the score words, max of their complements (= ~min) over valid entries
+  int valid = 0;
 #pragma unroll
-    for (int t = 0; t < N; ++t) c += __popcll(__ballot(e[t] >= trial));
-    if (c >= k) {
-      prefix = trial;
-      c_at = c;
-      if (c <= k + slack) break;
+  for (int t = 0; t < N; ++t) {
+    h[t] = (uint32_t)(e[t] >> 32);
+    mx = max(mx, h[t]);
+    nmn = max(nmn, e[t] != 0ull ? ~h[t] : 0u);
+    valid += __popcll(__ballot(e[t] != 0ull));
+  }
+  mx = wave_umax(mx);
+  const uint32_t mn = ~wave_umax(nmn);
+  const uint32_t diff = mx ^ mn;
+  uint32_t ph = diff ? (mx & ~((2u << (31 - __builtin_clz(diff))) - 1u)) : mx;   // the common high bits
+  int c_at = valid;
+  bool done = valid <= k + slack;
+  if (!done && diff) {
+#pragma unroll 1
+    for (int b = 31 - __builtin_clz(diff); b >= 0; --b) {
+      const uint32_t trial = ph | (1u << b);
+      int c = 0;
+#pragma unroll
+      for (int t = 0; t < N; ++t) c += __popcll(__ballot(h[t] >= trial));
+      if (c >= k) {
+        ph = trial;
+        c_at = c;
+        if (c <= k + slack) { done = true; break; }
+      }
+    }
+  }
+  uint64_t prefix = (uint64_t)ph << 32;
+  if (!done) {                                       // equal scores straddle the cut: decide by index (lower index = larger key)
+#pragma unroll 1
+    for (int b = 31; b >= 0; --b) {
+      const uint64_t trial = prefix | (1ull << b);
+      int c = 0;
+#pragma unroll
+      for (int t = 0; t < N; ++t) c += __popcll(__ballot(e[t] >= trial));
+      if (c >= k) {
+        prefix = trial;
+        c_at = c;
+        if (c <= k + slack) break;
+      }
     }
   }
   count = c_at;
   return prefix;
 }
 
-// Compaction of one query's LDS candidate buffer by the owning wave (all 64 lanes).  n > k + SLACK entries -> between k
-// and k + SLACK survivors, compacted in place; *cnt and *tau updated.  Only the owning wave touches the buffer and the LDS
-// operations of one wave execute in order, so no barrier is needed.
-__device__ __forceinline__ void compact_query(uint64_t *buf, int *cnt, float *tau, int k, int lane) {
-  const int n = __builtin_amdgcn_readfirstlane(*cnt);
-  if (n <= k + SLACK) return;
-  uint64_t e[EPL];
-#pragma unroll
-  for (int t = 0; t < EPL; ++t) e[t] = (lane + 64 * t < n) ? buf[lane + 64 * t] : 0ull;
-  int c;
-  const uint64_t p = bisect_kth<EPL>(e, k, SLACK, c);
+// Lanes of one wave hand data to each other through LDS (lane 0 publishes a count / threshold, every lane reads it).
+// The hardware executes a wave's LDS operations in order, but the COMPILER reasons per thread: without this barrier it
+// forwards a thread's own earlier load across another lane's store ("nobody in this thread wrote it").
+__device__ __forceinline__ void wave_lds_handoff() { asm volatile("" ::: "memory"); }
+
+// Compaction of one query's LDS candidate buffer by the owning wave (all 64 lanes).  The buffer is four lane-private
+// regions of REG entries (region g is appended to by lane (q, g) only, whose VGPR `my_cnt` is its fill level); n0..n3 are
+// the four levels.  More than k + SLACK entries -> between k and k + SLACK survivors, dealt round-robin back to the four
+// regions; returns the survivor count c (region g then holds (c - g + 3) / 4) and the new threshold.  Only the owning wave
+// touches the buffer and the LDS operations of one wave execute in order, so no barrier is needed.
+__device__ __forceinline__ int compact_query(uint64_t *buf, int n0, int n1, int n2, int n3, int k, int lane, float &new_tau) {
+  constexpr int GS = QW * REG;                         // region g of this query starts at buf + g * GS
+  wave_lds_handoff();
+  uint64_t e[4];
+  e[0] = lane < n0 ? buf[lane] : 0ull;
+  e[1] = lane < n1 ? buf[GS + lane] : 0ull;
+  e[2] = lane < n2 ? buf[2 * GS + lane] : 0ull;
+  e[3] = lane < n3 ? buf[3 * GS + lane] : 0ull;
+  int c = n0 + n1 + n2 + n3;
+  uint64_t p = 1ull;                                   // one region nearly full, few entries overall: only rebalance
+  if (c > k + SLACK) p = bisect_kth<4>(e, k, SLACK, c);
   int base = 0;
   const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int t = 0; t < EPL; ++t) {
+  for (int t = 0; t < 4; ++t) {
     const bool keep = e[t] >= p;
     const unsigned long long m = __ballot(keep);
-    if (keep) buf[base + __popcll(m & below)] = e[t];
+    const int r = base + __popcll(m & below);         // rank among the survivors -> region r & 3, slot r >> 2
+    if (keep) buf[(r & 3) * GS + (r >> 2)] = e[t];
     base += __popcll(m);
   }
+  wave_lds_handoff();
   // later positions have higher indices: one whose score EQUALS the cut's score loses the tie against all c >= k survivors
-  if (lane == 0) { *cnt = c; *tau = ord2f((uint32_t)(p >> 32)); }
+  if (p != 1ull) new_tau = ord2f((uint32_t)(p >> 32));
+  return c;
 }
 
 struct SelectArgs {
@@ -114,14 +177,15 @@ struct SelectArgs {
   int tps;                // tiles per stream
   long long total_tiles;
   int tiles_per_wg, slots, L;
+  unsigned long long *dbg;   // profiling builds: {shader cycles, tiles} of workgroup 0 / wave 0 (NULL otherwise)
 };
 
-template <int ABL>   // ablation switch for profiling builds (0 = product, 1 = MFMA + staging only)
+// ABL: ablation switch for profiling builds (0 = product, 1 = MFMA + staging only).
+template <int ABL>
 __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs a) {
   __shared__ __attribute__((aligned(16))) float ktile[2][KT * KLD];
-  __shared__ uint64_t cand[QT * CAP];
-  __shared__ int cnt[QT];
-  __shared__ float tau[QT];
+  __shared__ uint64_t cand[QT * CAP];                 // [wave][g][q][REG]
+  __shared__ uint64_t dump[256];                      // where the (branch-free) appends of non-passing lanes go
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int jq = lane & 15, g = lane >> 4;
@@ -134,6 +198,7 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
 
   long long t_begin = (long long)blockIdx.x * a.tiles_per_wg;
   const long long t_end = (t_begin + a.tiles_per_wg < a.total_tiles) ? t_begin + a.tiles_per_wg : a.total_tiles;
+  const unsigned long long clk0 = (a.dbg && blockIdx.x == 0) ? __builtin_readcyclecounter() : 0ull;
 
   while (t_begin < t_end) {
     const int stream = (int)(t_begin / a.tps);
@@ -149,7 +214,6 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
     const float *kbase = a.keys + (long long)obj * a.keys_ostride;
 
     __syncthreads();                                  // previous segment completely done with LDS
-    if (tid < QT) { cnt[tid] = 0; tau[tid] = -INFINITY; }
 
     // B operand: this lane's query row pieces, scaled like prop_net.py:86 (qk / sqrt(CK), a true division)
     f32x4_t qreg[8];
@@ -165,93 +229,119 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
       }
     }
 
-    f32x4_t kr[4];
-    auto gload = [&](int kb) {
+    // global -> register staging of key tiles, two sets in flight (a tile is requested two iterations before it is
+    // written to LDS: one iteration, ~1 us, is shorter than the L2 latency when a dozen workgroups stream the same keys)
+    f32x4_t krA[4], krB[4];
+    auto gload = [&](f32x4_t (&kr)[4], int kb) {
+      // rows past the end of the segment are read from its first row instead: their scores are never selected (row < r1
+      // in slice_a), and touching the loaded values here (zero-filling) would make the wave wait for the load right away
       const int m = kb + lrow;
-      const bool ok = m < r1;
-      const f32x4_t *src = reinterpret_cast<const f32x4_t *>(kbase + (long long)(ok ? m : r0) * CK) + lc;
+      const f32x4_t *src = reinterpret_cast<const f32x4_t *>(kbase + (long long)(m < r1 ? m : r0) * CK) + lc;
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        f32x4_t v = src[8 * jj];
-        if (!ok) { v.x = v.y = v.z = v.w = 0.f; }
-        kr[jj] = v;
-      }
+      for (int jj = 0; jj < 4; ++jj) kr[jj] = src[8 * jj];
     };
-    auto lds_store = [&](int buf) {
+    auto lds_store = [&](f32x4_t (&kr)[4], int buf) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4_t *>(&ktile[buf][lrow * KLD + 4 * (lc + 8 * jj)]) = kr[jj];
     };
-    gload(r0);
-    lds_store(0);
-    if (nt > 1) gload(r0 + KT);
-    __syncthreads();
 
     // scores of the previous tile (software pipeline): -inf = nothing to select on the first tile
     f32x4_t p0 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, p1 = p0;
     int pb = r0;                                      // base row of the previous tile
     float my_tau = -INFINITY;
 
-    // one selection step: score register (sub, r) of the previous tile; the slot reservation (LDS atomic) issued in step i
-    // is consumed in step i + 1, after the 8 MFMAs in between
-    int pend_pos = 0;
-    bool pend = false;
-    uint64_t pend_ent = 0ull;
-    auto flush_pending = [&]() {
-      if (pend) cand[qslot * CAP + pend_pos] = pend_ent;
-      pend = false;
-    };
-    auto select_step = [&](int i) {
-      flush_pending();
+    // Selection of score register i (sub-tile i>>2, row 4g + (i&3)) of the previous tile, BRANCH-FREE and cut into three
+    // slices that are placed between the MFMAs of the running tile: every lane takes part in the LDS atomic (adding 0 when
+    // its score does not pass) and in the candidate store (to a private dump slot when it does not pass), so the whole tile
+    // is one basic block and the slices issue in the shadow of the matrix pipe.
+    // Lane (q, g) appends to ITS region of query q's buffer at its private fill level: no atomic, no LDS round trip.
+    uint64_t *const my_region = cand + ((wave * 4 + g) * QW + jq) * REG;
+    int my_cnt = 0;
+    bool s_pass;
+    uint32_t s_ord, s_nidx;
+    auto slice_a = [&](int i) {                       // compare
       const float sc = (i < 4) ? p0[i & 3] : p1[i & 3];
-      const int rowoff = 16 * (i >> 2) + 4 * g + (i & 3);
-      const bool pass = sc > my_tau && (pb + rowoff < r1);
-      if (pass) {
-        pend_pos = atomicAdd(&cnt[qslot], 1);
-        pend_ent = pack_cand(sc, (uint32_t)(pb + rowoff));
-      }
-      pend = pass;
+      const int row = pb + 16 * (i >> 2) + 4 * g + (i & 3);
+      s_pass = sc > my_tau && row < r1;
+    };
+    auto slice_b = [&](int i) {                       // pack {orderable score, ~index}
+      const float sc = (i < 4) ? p0[i & 3] : p1[i & 3];
+      s_ord = f2ord(sc);
+      s_nidx = ~(uint32_t)(pb + 16 * (i >> 2) + 4 * g + (i & 3));
+    };
+    auto slice_c = [&]() {                            // store, bump the private fill level
+      uint64_t *dst = s_pass ? my_region + my_cnt : &dump[tid];
+      *dst = ((uint64_t)s_ord << 32) | (uint64_t)s_nidx;
+      my_cnt += s_pass ? 1 : 0;
+    };
+    // compaction of query `ql` (0..15) of this wave: fill levels come from the four owner lanes, go back to them
+    auto compact_one = [&](int ql, bool force) {
+      const int n0 = __builtin_amdgcn_readlane(my_cnt, ql), n1 = __builtin_amdgcn_readlane(my_cnt, ql + 16);
+      const int n2 = __builtin_amdgcn_readlane(my_cnt, ql + 32), n3 = __builtin_amdgcn_readlane(my_cnt, ql + 48);
+      if (force && n0 + n1 + n2 + n3 <= a.top_k + SLACK) return;   // end of a segment: the list takes the regions as they are
+      float nt_tau = my_tau;                                       // (unchanged when nothing is dropped)
+      const int c = compact_query(cand + (wave * 4 * QW + ql) * REG, n0, n1, n2, n3, a.top_k, lane, nt_tau);
+      if (jq == ql) { my_cnt = (c - g + 3) >> 2; my_tau = nt_tau; }
     };
     auto make_room = [&]() {
-      // before the (up to 32 per query) appends of a tile: compact every buffer of this wave that might overflow
-      const int mycnt = cnt[qslot];
-      unsigned long long need = __ballot(mycnt > CAP_TRIGGER) & 0xffffull;
-      if (need) {
-        while (need) {
-          const int s = wave * QW + __builtin_ctzll(need);
-          need &= need - 1;
-          compact_query(cand + s * CAP, cnt + s, tau + s, a.top_k, lane);
-        }
-        my_tau = tau[qslot];
+      // before the (up to 8 per lane) appends of a tile: compact every buffer of this wave with a region that might overflow
+      const unsigned long long full = __ballot(my_cnt > REG_TRIGGER);
+      unsigned need = (unsigned)((full | (full >> 16) | (full >> 32) | (full >> 48)) & 0xffffull);
+      while (need) {
+        const int ql = __builtin_ctz(need);
+        need &= need - 1;
+        compact_one(ql, false);
       }
     };
 
-    for (int t = 0; t < nt; ++t) {
-      const int cur = t & 1;
-      const float *arow0 = &ktile[cur][jq * KLD + coff];
-      const float *arow1 = arow0 + 16 * KLD;
-      f32x4_t af0[8], af1[8];
+    // Prologue.  The A fragments of tile t+1 are read from LDS into a second register set DURING the MFMAs of tile t (two
+    // ds_read_b128 per 8 MFMAs) instead of in one burst after the barrier; tile t+2 is then written over tile t's LDS copy
+    // (dead once every wave holds it in registers), so two LDS buffers suffice and there is one barrier per tile.
+    f32x4_t fa0[8], fa1[8], fb0[8], fb1[8];
+    gload(krA, r0);
+    if (nt > 1) gload(krB, r0 + KT);
+    lds_store(krA, 0);
+    if (nt > 1) lds_store(krB, 1);
+    if (nt > 2) gload(krA, r0 + 2 * KT);
+    if (nt > 3) gload(krB, r0 + 3 * KT);
+    __syncthreads();
+    {
+      const float *arow0 = &ktile[0][jq * KLD + coff];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        af0[u] = *reinterpret_cast<const f32x4_t *>(arow0 + 4 * u);
-        af1[u] = *reinterpret_cast<const f32x4_t *>(arow1 + 4 * u);
+        fa0[u] = *reinterpret_cast<const f32x4_t *>(arow0 + 4 * u);
+        fa1[u] = *reinterpret_cast<const f32x4_t *>(arow0 + 16 * KLD + 4 * u);
       }
-      if (t + 1 < nt) lds_store(cur ^ 1);             // tile t+1 (its buffer was last read in iteration t-1)
-      if (t + 2 < nt) gload(r0 + (t + 2) * KT);
-      if (ABL == 0) make_room();
+    }
+    __syncthreads();                                  // every wave holds tile 0 in registers: its LDS copy is dead
 
+    // one tile: MFMAs on fragment set F (tile t) while G receives tile t+1's fragments and tile t-1's scores are selected
+    auto tile_iter = [&](int t, f32x4_t (&F0)[8], f32x4_t (&F1)[8], f32x4_t (&G0)[8], f32x4_t (&G1)[8], f32x4_t (&kr)[4]) {
+      if (t + 2 < nt) lds_store(kr, t & 1);           // tile t+2 (requested in iteration t-2) over tile t's (dead) LDS copy
+      if (t + 4 < nt) gload(kr, r0 + (t + 4) * KT);
+      if (ABL == 0) make_room();
+      const float *nrow0 = &ktile[(t + 1) & 1][jq * KLD + coff];   // tile t+1 (stale data past the segment's end: unused)
       f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#define MIVOS_MF(U, S)                                                                                   \
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F0[U][S], qreg[U][S], acc0, 0, 0, 0);                      \
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F1[U][S], qreg[U][S], acc1, 0, 0, 0);                      \
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        if (ABL == 0) select_step(u);
+        if (ABL == 0) slice_a(u);
+        G0[u] = *reinterpret_cast<const f32x4_t *>(nrow0 + 4 * u);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af0[u][s], qreg[u][s], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af1[u][s], qreg[u][s], acc1, 0, 0, 0);
-        }
+        MIVOS_MF(u, 0)
+        if (ABL == 0) slice_b(u);
+        G1[u] = *reinterpret_cast<const f32x4_t *>(nrow0 + 16 * KLD + 4 * u);
         __builtin_amdgcn_sched_barrier(0);
+        MIVOS_MF(u, 1)
+        MIVOS_MF(u, 2)
+        if (ABL == 0) slice_c();
+        __builtin_amdgcn_sched_barrier(0);
+        MIVOS_MF(u, 3)
       }
-      if (ABL == 0) flush_pending();
+#undef MIVOS_MF
       if (ABL == 1 && t >= 2) {                        // keep the MFMA results alive without selecting
         const float sum = (acc0.x + acc0.y) + (acc1.z + acc1.w);
         if (sum == 123.456f) my_tau = sum;
@@ -260,22 +350,37 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
         pb = r0 + t * KT;
       }
       __syncthreads();
+    };
+    for (int t = 0; t < nt; t += 2) {
+      tile_iter(t, fa0, fa1, fb0, fb1, krA);
+      if (t + 1 < nt) tile_iter(t + 1, fb0, fb1, fa0, fa1, krB);
     }
     // drain the pipeline: select on the last tile
     make_room();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) select_step(i);
-    flush_pending();
+    for (int i = 0; i < 8; ++i) { slice_a(i); slice_b(i); slice_c(); }
 
     // this segment's candidate lists: for each of the wave's 16 queries between min(n, k) and k + SLACK entries
-    for (int qs = 0; qs < QW; ++qs) {
-      const int s = wave * QW + qs;
-      compact_query(cand + s * CAP, cnt + s, tau + s, a.top_k, lane);
-      const int n = cnt[s];                           // <= k + SLACK = L
+    for (int ql = 0; ql < QW; ++ql) {
+      compact_one(ql, true);
+      wave_lds_handoff();
+      const int n0 = __builtin_amdgcn_readlane(my_cnt, ql), n1 = __builtin_amdgcn_readlane(my_cnt, ql + 16);
+      const int n2 = __builtin_amdgcn_readlane(my_cnt, ql + 32), n3 = __builtin_amdgcn_readlane(my_cnt, ql + 48);
+      const int s = wave * QW + ql;
+      const uint64_t *src = cand + (wave * 4 * QW + ql) * REG;     // region g at src + g * QW * REG
       uint64_t *dst = a.lists + (((long long)stream * a.slots + slot) * QT + s) * a.L;
-      for (int i = lane; i < a.L; i += 64) dst[i] = (i < n) ? cand[s * CAP + i] : 0ull;
+      // n0 + n1 + n2 + n3 <= k + SLACK = L <= 80: lanes 0..REG-1 copy one entry of each region, the rest is zero-filled
+      if (lane < n0) dst[lane] = src[lane];
+      if (lane < n1) dst[n0 + lane] = src[QW * REG + lane];
+      if (lane < n2) dst[n0 + n1 + lane] = src[2 * QW * REG + lane];
+      if (lane < n3) dst[n0 + n1 + n2 + lane] = src[3 * QW * REG + lane];
+      for (int i = n0 + n1 + n2 + n3 + lane; i < a.L; i += 64) dst[i] = 0ull;
     }
     t_begin += nt;
+  }
+  if (a.dbg && blockIdx.x == 0 && tid == 0) {
+    a.dbg[0] = __builtin_readcyclecounter() - clk0;
+    a.dbg[1] = (unsigned long long)(t_end - (long long)blockIdx.x * a.tiles_per_wg);
   }
 }
 
@@ -295,6 +400,9 @@ __global__ __launch_bounds__(64) void memread_finalize_kernel(const uint64_t *__
   const int lane = threadIdx.x;
   const int q = blockIdx.x, obj = blockIdx.y;
   const int stream = obj * n_qtiles + q / QT, qs = q % QT;
+  // defined contents whatever the lists hold (ablation builds leave them incomplete): position 0, weight 0
+  sel[lane] = pack_cand(-INFINITY, 0u); oi[lane] = 0u; ow[lane] = 0.f; wv[lane] = 0.f;
+  __syncthreads();
   // the segments of this stream: workgroups w_first .. w_last of the select kernel
   const int w_first = (int)(((long long)stream * tps) / tiles_per_wg);
   const int w_last = (int)((((long long)stream + 1) * tps - 1) / tiles_per_wg);
@@ -467,11 +575,25 @@ extern "C" int mivos_memory_read_select(const float *keys, int64_t keys_ostride,
   a.keys = keys; a.keys_ostride = keys_ostride; a.qk = qk; a.lists = (uint64_t *)workspace; a.n_mem = n_mem; a.n_q = n_q;
   a.top_k = top_k; a.n_qtiles = pl.n_qtiles; a.tps = pl.tps; a.total_tiles = pl.total; a.tiles_per_wg = pl.tiles_per_wg;
   a.slots = pl.slots; a.L = pl.L;
-  static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;   // profiling only
+  static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;          // profiling only
+  static const int dbg = getenv("MIVOS_MEMREAD_DBG") ? atoi(getenv("MIVOS_MEMREAD_DBG")) : 0;   // profiling only: prints cycles per tile
+  static unsigned long long *dbg_buf = nullptr;
+  a.dbg = nullptr;
+  if (dbg) {
+    if (!dbg_buf && hipMalloc((void **)&dbg_buf, 16) != hipSuccess) dbg_buf = nullptr;
+    a.dbg = dbg_buf;
+  }
   if (abl == 1)
     hipLaunchKernelGGL(memread_select_kernel<1>, dim3(pl.n_wg), dim3(256), 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(memread_select_kernel<0>, dim3(pl.n_wg), dim3(256), 0, (hipStream_t)stream, a);
+  if (dbg && dbg_buf) {
+    unsigned long long h[2] = {0, 0};
+    hipStreamSynchronize((hipStream_t)stream);
+    hipMemcpy(h, dbg_buf, 16, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[memread_select] n_obj=%d n_mem=%lld n_q=%d: workgroup 0 ran %llu tiles in %llu shader-clock ticks = %.0f per tile (ideal 2048 MFMA cycles)\n",
+            n_obj, (long long)n_mem, n_q, h[1], h[0], h[1] ? (double)h[0] / (double)h[1] : 0.0);
+  }
   return check_launch("memread_select");
 }
 

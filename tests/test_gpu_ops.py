@@ -291,7 +291,10 @@ def test_aggregate_argmax_diff_others(golden_dir):
     many = torch.rand(40, 1, 16, 24, generator=g) * 0.2       # more objects than the register-cached variant holds (32)
     for hard in (False, True):
         got = ops.aggregate(many.to(DEV), keep_bg=True, hard=hard).cpu()
-        assert got.shape == (41, 1, 16, 24) and float((got - O.aggregate_wbg(many, True, hard=hard)).abs().max()) < 2e-6
+        ref = O.aggregate_wbg(many, True, hard=hard)
+        # hard: logits x 1000, so a 1-ulp difference of logf moves exp(l - max) by 1e-4 relative; the winner must be the same
+        assert got.shape == (41, 1, 16, 24) and float((got - ref).abs().max()) < (5e-4 if hard else 2e-6)
+        assert torch.equal(got.argmax(0), ref.argmax(0))
     prob = torch.rand(4, 7, 1, 16, 24, generator=g)
     prob[2, 3] = prob[1, 3]                                   # ties: first index must win
     got = ops.argmax_u8(prob.to(DEV).view(4, -1)).cpu().view(7, 1, 16, 24)
@@ -345,19 +348,24 @@ def test_memory_read_golden(golden_dir):
                                            (7, 30, 54, 5, 50),      # the benchmark's shape: runs that cross stream boundaries
                                            (2, 68, 120, 1, 64)])    # 1080p grid, largest supported k
 def test_memory_read_vs_oracle(T, h, w, K, top_k):
+    """Readout and exact top-k membership.  A query whose k-th and (k+1)-th scores tie within fp32 rounding (the case
+    T=23 holds one with a margin of exactly 0 in torch's own fp32 affinity) may legitimately resolve either way -
+    torch.topk leaves ties unspecified and the summation order of the 128-term dot product is implementation defined -
+    so values and index sets are compared on the queries with a clear margin (all but <= 1 % / two of them)."""
     mk, mv, qk = _mem_case(T, h, w, K, seed=T * 100 + K)
     got, idx, wgt = _run_mem(mk, mv, qk, top_k)
     for o in range(K):
         ref = O.memory_read(mk[o:o + 1], mv[o:o + 1], qk, top_k)
-        assert float((got[o:o + 1] - ref).abs().max()) < 2e-4
-        # exact top-k membership: compare index sets where the k-th / (k+1)-th scores are not a near tie
         a = O.affinity(mk[o:o + 1], qk)[0]                      # [THW, HW]
-        vals, ridx = torch.topk(a, top_k + 1, dim=0)
-        clear = (vals[top_k - 1] - vals[top_k]) > 1e-5
+        vals, ridx = torch.topk(a, min(top_k + 1, a.shape[0]), dim=0)
+        clear = (vals[top_k - 1] - vals[top_k]) > 1e-5 if a.shape[0] > top_k else torch.ones(a.shape[1], dtype=torch.bool)
+        d = (got[o] - ref[0]).abs().amax(0).reshape(-1)         # per query, max over the 512 channels
+        assert float(d[clear].max()) < 2e-4 and int((~clear).sum()) <= max(2, clear.numel() // 100)
+        assert float(d.max()) < 0.5                             # a flipped tie swaps ONE neighbour of weight ~1/k
         got_sets = torch.sort(idx[o].long(), dim=1)[0]          # [HW, k]
         ref_sets = torch.sort(ridx[:top_k].t(), dim=1)[0]
         same = (got_sets == ref_sets).all(dim=1)
-        assert bool(same[clear].all()) and float(clear.float().mean()) > 0.99
+        assert bool(same[clear].all())
         assert torch.equal(idx[o][:, 0].long()[clear], ridx[0][clear])          # best first
         assert float((wgt[o].sum(1) - 1).abs().max()) < 1e-5
 
