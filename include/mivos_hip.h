@@ -137,6 +137,22 @@ int mivos_maxpool3x3s2(const float *x, float *y, int N, int H, int W, int C, voi
 int mivos_upsample2x_add(const float *skip, int64_t skip_nstride, const float *up, float *out,
                          int N, int h, int w, int C, void *stream);
 
+/* The same with up to three outputs (any may be NULL) that feed the next layers without a conversion pass: `out` dense
+ * fp32 NHWC, `raw_sh32` the sum in SH32 and `relu_sh32` = SH32 of max(sum, 0) (pre-activation ResBlocks, modules.py:28-35:
+ * a DMA-staged operand cannot be modified on load, so its producer applies the ReLU).  The SH32 outputs point at interior
+ * pixel (0, 0) of image 0 of zero-bordered buffers with the given strides (floats). */
+int mivos_upsample2x_add_multi(const float *skip, int64_t skip_nstride, const float *up, float *out, void *raw_sh32,
+                               void *relu_sh32, int64_t a_nstride, int64_t a_rstride, int64_t a_pstride, int N, int h,
+                               int w, int C, void *stream);
+/* mivos_maxpool3x3s2 writing SH32 into a zero-bordered buffer (C % 32 == 0). */
+int mivos_maxpool3x3s2_sh32(const float *x, void *y_sh32, int64_t y_nstride, int64_t y_rstride, int64_t y_pstride, int N,
+                            int H, int W, int C, void *stream);
+/* Second half of a 3x3 / pad 1 convolution with ONE output channel (decoder `pred`, prop_net.py:22,29; FusionNet
+ * `final_conv`, fusion_net.py:30,49): t [N][H][W][16] holds per input pixel the nine tap products t[p][k] = w[k] . x[p]
+ * (a 1x1 projection computed by mivos_conv2d_fused, which reads x exactly once instead of nine times);
+ * out[n][y][x] = bias[0] + sum_k t[n][y + k/3 - 1][x + k%3 - 1][k], zero outside the image.  out: planar [N][H*W]. */
+int mivos_tap_sum9(const float *t, const float *bias, float *out, int N, int H, int W, void *stream);
+
 /* --------------------------------------------------------------------------------------------
  * Space-time memory read: affinity (MFMA) -> streaming per-query top-k -> softmax over the k
  * survivors -> sparse value readout.  Replaces EvalMemoryReader.forward + softmax_w_g_top
@@ -168,6 +184,14 @@ int mivos_memory_read_select(const float *keys, int64_t keys_ostride, const floa
 int mivos_memory_read_finalize(const float *values, int64_t values_ostride, float *out,
                                int64_t out_ostride, int64_t out_pstride, int n_obj, int64_t n_mem,
                                int n_q, int top_k, void *workspace, int64_t workspace_bytes, void *stream);
+/* mivos_memory_read_finalize writing the readout pre-split for the LDS-DMA convolutions instead of as fp32 rows: SH32 of
+ * the 512 channels (`raw_sh32`) and of their ReLU (`relu_sh32`; either may be NULL) at image o, pixel (q / q_width,
+ * q % q_width) of zero-bordered buffers with the given strides (floats) - the decoder's first ResBlock (prop_net.py:24,
+ * modules.py:28-35) reads relu(x) and x, so no conversion pass is needed between the read and the decoder. */
+int mivos_memory_read_finalize_sh32(const float *values, int64_t values_ostride, void *raw_sh32, void *relu_sh32,
+                                    int64_t a_nstride, int64_t a_rstride, int64_t a_pstride, int q_width, int n_obj,
+                                    int64_t n_mem, int n_q, int top_k, void *workspace, int64_t workspace_bytes,
+                                    void *stream);
 /* Debug/test export: same selection, but writes the k selected memory indices (ascending score
  * rank, best first) and their normalised softmax weights instead of the readout. */
 int mivos_memory_read_topk_indices(const float *keys, int64_t keys_ostride, const float *qk,

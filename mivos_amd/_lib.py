@@ -47,11 +47,15 @@ PROTOTYPES = {
     "mivos_conv2d_variant_pp": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "mivos_maxpool3x3s2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_upsample2x_add": (C.c_int, [vp, i64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_upsample2x_add_multi": (C.c_int, [vp, i64, vp, vp, vp, vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_maxpool3x3s2_sh32": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_tap_sum9": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_memory_read_workspace_bytes": (i64, [C.c_int, i64, C.c_int, C.c_int]),
     "mivos_memory_read_topk": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
     "mivos_memory_read_plan": (C.c_int, [C.c_int, i64, C.c_int, C.c_int, C.POINTER(i32)]),
     "mivos_memory_read_select": (C.c_int, [vp, i64, vp, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
     "mivos_memory_read_finalize": (C.c_int, [vp, i64, vp, i64, i64, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
+    "mivos_memory_read_finalize_sh32": (C.c_int, [vp, i64, vp, vp, i64, i64, i64, C.c_int, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
     "mivos_memory_read_topk_indices": (C.c_int, [vp, i64, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
     "mivos_attention_align": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "mivos_area_pool16": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -26,7 +26,7 @@
 //   in ascending memory index - the order in which the reference's dense bmm meets its non-zeros.
 #include <stdlib.h>
 
-#include "common.h"
+#include "conv_common.h"
 
 namespace mivos {
 
@@ -140,14 +140,25 @@ __device__ __forceinline__ void wave_lds_handoff() { asm volatile("" ::: "memory
 // the four levels.  More than k + SLACK entries -> between k and k + SLACK survivors, dealt round-robin back to the four
 // regions; returns the survivor count c (region g then holds (c - g + 3) / 4) and the new threshold.  Only the owning wave
 // touches the buffer and the LDS operations of one wave execute in order, so no barrier is needed.
+// LDS candidate entries are RAW {score bits (high word), memory index (low word)}: the append path runs for every score of
+// every tile (and a wave's vector instructions are not hidden behind its own fp32 MFMAs - they share the SIMD's FMA lanes),
+// so the conversion to the orderable key {f2ord(score), ~index} happens where entries are read back (compaction, list copy).
+__device__ __forceinline__ uint64_t raw_to_key(uint64_t raw) {
+  return ((uint64_t)f2ord(__uint_as_float((uint32_t)(raw >> 32))) << 32) | (uint64_t)(~(uint32_t)raw);
+}
+
 __device__ __forceinline__ int compact_query(uint64_t *buf, int n0, int n1, int n2, int n3, int k, int lane, float &new_tau) {
   constexpr int GS = QW * REG;                         // region g of this query starts at buf + g * GS
   wave_lds_handoff();
-  uint64_t e[4];
-  e[0] = lane < n0 ? buf[lane] : 0ull;
-  e[1] = lane < n1 ? buf[GS + lane] : 0ull;
-  e[2] = lane < n2 ? buf[2 * GS + lane] : 0ull;
-  e[3] = lane < n3 ? buf[3 * GS + lane] : 0ull;
+  uint64_t raw[4], e[4];
+  raw[0] = lane < n0 ? buf[lane] : 0ull;
+  raw[1] = lane < n1 ? buf[GS + lane] : 0ull;
+  raw[2] = lane < n2 ? buf[2 * GS + lane] : 0ull;
+  raw[3] = lane < n3 ? buf[3 * GS + lane] : 0ull;
+  e[0] = lane < n0 ? raw_to_key(raw[0]) : 0ull;
+  e[1] = lane < n1 ? raw_to_key(raw[1]) : 0ull;
+  e[2] = lane < n2 ? raw_to_key(raw[2]) : 0ull;
+  e[3] = lane < n3 ? raw_to_key(raw[3]) : 0ull;
   int c = n0 + n1 + n2 + n3;
   uint64_t p = 1ull;                                   // one region nearly full, few entries overall: only rebalance
   if (c > k + SLACK) p = bisect_kth<4>(e, k, SLACK, c);
@@ -158,7 +169,7 @@ __device__ __forceinline__ int compact_query(uint64_t *buf, int n0, int n1, int 
     const bool keep = e[t] >= p;
     const unsigned long long m = __ballot(keep);
     const int r = base + __popcll(m & below);         // rank among the survivors -> region r & 3, slot r >> 2
-    if (keep) buf[(r & 3) * GS + (r >> 2)] = e[t];
+    if (keep) buf[(r & 3) * GS + (r >> 2)] = raw[t];
     base += __popcll(m);
   }
   wave_lds_handoff();
@@ -185,7 +196,6 @@ template <int ABL>
 __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs a) {
   __shared__ __attribute__((aligned(16))) float ktile[2][KT * KLD];
   __shared__ uint64_t cand[QT * CAP];                 // [wave][g][q][REG]
-  __shared__ uint64_t dump[256];                      // where the (branch-free) appends of non-passing lanes go
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int jq = lane & 15, g = lane >> 4;
@@ -198,7 +208,9 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
 
   long long t_begin = (long long)blockIdx.x * a.tiles_per_wg;
   const long long t_end = (t_begin + a.tiles_per_wg < a.total_tiles) ? t_begin + a.tiles_per_wg : a.total_tiles;
-  const unsigned long long clk0 = (a.dbg && blockIdx.x == 0) ? __builtin_readcyclecounter() : 0ull;
+  const bool prof = a.dbg && blockIdx.x == 0;       // profiling builds only (MIVOS_MEMREAD_DBG)
+  const unsigned long long clk0 = prof ? __builtin_readcyclecounter() : 0ull;
+  unsigned long long clk_room = 0ull, clk_final = 0ull, clk_pro = 0ull, n_compact = 0ull;
 
   while (t_begin < t_end) {
     const int stream = (int)(t_begin / a.tps);
@@ -257,22 +269,38 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
     // Lane (q, g) appends to ITS region of query q's buffer at its private fill level: no atomic, no LDS round trip.
     uint64_t *const my_region = cand + ((wave * 4 + g) * QW + jq) * REG;
     int my_cnt = 0;
+    // Append path, per score register: ONE vector compare, the index (one subtract from a per-tile base), the LDS address
+    // (fill level * 8 + region), a store executed by the passing lanes only (exec := the compare's mask around one
+    // ds_write2_b32; no branch) and an add-with-carry of the mask into the fill level.  Measured (MIVOS_ABL=2..4): a wave's
+    // VALU / LDS-store instructions cost their full issue time next to its own fp32 MFMAs - nothing here is hidden - so the
+    // instruction count is the cost; entries stay raw {score bits, index}, the orderable key is built at compaction time.
+    const uint32_t region_lds = (uint32_t)(size_t)my_region;     // LDS byte address of this lane's region
     bool s_pass;
-    uint32_t s_ord, s_nidx;
-    auto slice_a = [&](int i) {                       // compare
-      const float sc = (i < 4) ? p0[i & 3] : p1[i & 3];
-      const int row = pb + 16 * (i >> 2) + 4 * g + (i & 3);
-      s_pass = sc > my_tau && row < r1;
-    };
-    auto slice_b = [&](int i) {                       // pack {orderable score, ~index}
-      const float sc = (i < 4) ? p0[i & 3] : p1[i & 3];
-      s_ord = f2ord(sc);
-      s_nidx = ~(uint32_t)(pb + 16 * (i >> 2) + 4 * g + (i & 3));
-    };
-    auto slice_c = [&]() {                            // store, bump the private fill level
-      uint64_t *dst = s_pass ? my_region + my_cnt : &dump[tid];
-      *dst = ((uint64_t)s_ord << 32) | (uint64_t)s_nidx;
+    uint32_t idx_base = 0u;                           // pb + 4g: index of (sub, r) = idx_base + 16 sub + r
+    auto slice_a = [&](int i) { s_pass = ((i < 4) ? p0[i & 3] : p1[i & 3]) > my_tau; };
+    auto slice_b = [&](int i) {
+      const unsigned long long m = __ballot(s_pass);
+      const uint32_t addr = region_lds + 8u * (uint32_t)my_cnt;
+      const uint32_t idx = idx_base + (uint32_t)(16 * (i >> 2) + (i & 3));
+      const uint32_t bits = __float_as_uint((i < 4) ? p0[i & 3] : p1[i & 3]);
+      unsigned long long saved;
+      asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write2_b32 %2, %3, %4 offset1:1\n\ts_mov_b64 exec, %0"
+                   : "=&s"(saved) : "s"(m), "v"(addr), "v"(idx), "v"(bits) : "memory");
       my_cnt += s_pass ? 1 : 0;
+    };
+    // latch the scores of tile t for the selection that runs during tile t+1; only the last tile of a stream can hold rows
+    // past the end of the memory (scores of whatever row was loaded instead): those become -inf here
+    auto latch_scores = [&](const f32x4_t &a0, const f32x4_t &a1, int t) {
+      p0 = a0; p1 = a1;
+      pb = r0 + t * KT;
+      idx_base = (uint32_t)(pb + 4 * g);
+      if (pb + KT > r1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (pb + 4 * g + i >= r1) p0[i] = -INFINITY;
+          if (pb + 16 + 4 * g + i >= r1) p1[i] = -INFINITY;
+        }
+      }
     };
     // compaction of query `ql` (0..15) of this wave: fill levels come from the four owner lanes, go back to them
     auto compact_one = [&](int ql, bool force) {
@@ -287,13 +315,19 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
       // before the (up to 8 per lane) appends of a tile: compact every buffer of this wave with a region that might overflow
       const unsigned long long full = __ballot(my_cnt > REG_TRIGGER);
       unsigned need = (unsigned)((full | (full >> 16) | (full >> 32) | (full >> 48)) & 0xffffull);
-      while (need) {
-        const int ql = __builtin_ctz(need);
-        need &= need - 1;
-        compact_one(ql, false);
+      if (need) {
+        const unsigned long long c0 = prof ? __builtin_readcyclecounter() : 0ull;
+        while (need) {
+          const int ql = __builtin_ctz(need);
+          need &= need - 1;
+          compact_one(ql, false);
+          n_compact += prof ? 1 : 0;
+        }
+        if (prof) clk_room += __builtin_readcyclecounter() - c0;
       }
     };
 
+    const unsigned long long cpro = prof ? __builtin_readcyclecounter() : 0ull;
     // Prologue.  The A fragments of tile t+1 are read from LDS into a second register set DURING the MFMAs of tile t (two
     // ds_read_b128 per 8 MFMAs) instead of in one burst after the barrier; tile t+2 is then written over tile t's LDS copy
     // (dead once every wave holds it in registers), so two LDS buffers suffice and there is one barrier per tile.
@@ -315,6 +349,7 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
     }
     __syncthreads();                                  // every wave holds tile 0 in registers: its LDS copy is dead
 
+    if (prof) clk_pro += __builtin_readcyclecounter() - cpro;
     // one tile: MFMAs on fragment set F (tile t) while G receives tile t+1's fragments and tile t-1's scores are selected
     auto tile_iter = [&](int t, f32x4_t (&F0)[8], f32x4_t (&F1)[8], f32x4_t (&G0)[8], f32x4_t (&G1)[8], f32x4_t (&kr)[4]) {
       if (t + 2 < nt) lds_store(kr, t & 1);           // tile t+2 (requested in iteration t-2) over tile t's (dead) LDS copy
@@ -322,32 +357,38 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
       if (ABL == 0) make_room();
       const float *nrow0 = &ktile[(t + 1) & 1][jq * KLD + coff];   // tile t+1 (stale data past the segment's end: unused)
       f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#define MIVOS_MF(U, S)                                                                                   \
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F0[U][S], qreg[U][S], acc0, 0, 0, 0);                      \
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F1[U][S], qreg[U][S], acc1, 0, 0, 0);                      \
-  __builtin_amdgcn_sched_barrier(0);
+      // A single wave issues a vector instruction every ~8 cycles, an MFMA occupies the matrix pipe for 32: at most ~3 other
+      // instructions fit behind each MFMA, and everything beyond that in one gap idles the pipe (measured: clusters of 5-6
+      // cost their full issue time).  So the selection is dealt out ONE OR TWO instructions per MFMA, pinned by scheduling
+      // barriers (the compiler would otherwise regroup them).
+#define MIVOS_SB __builtin_amdgcn_sched_barrier(0);
+#define MIVOS_MF0(U, S) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F0[U][S], qreg[U][S], acc0, 0, 0, 0); MIVOS_SB
+#define MIVOS_MF1(U, S) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F1[U][S], qreg[U][S], acc1, 0, 0, 0); MIVOS_SB
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        if (ABL == 0) slice_a(u);
-        G0[u] = *reinterpret_cast<const f32x4_t *>(nrow0 + 4 * u);
-        __builtin_amdgcn_sched_barrier(0);
-        MIVOS_MF(u, 0)
-        if (ABL == 0) slice_b(u);
-        G1[u] = *reinterpret_cast<const f32x4_t *>(nrow0 + 16 * KLD + 4 * u);
-        __builtin_amdgcn_sched_barrier(0);
-        MIVOS_MF(u, 1)
-        MIVOS_MF(u, 2)
-        if (ABL == 0) slice_c();
-        __builtin_amdgcn_sched_barrier(0);
-        MIVOS_MF(u, 3)
+        G0[u] = *reinterpret_cast<const f32x4_t *>(nrow0 + 4 * u); MIVOS_SB
+        MIVOS_MF0(u, 0)
+        if (ABL != 1) slice_a(u);
+        MIVOS_SB
+        MIVOS_MF1(u, 0)
+        G1[u] = *reinterpret_cast<const f32x4_t *>(nrow0 + 16 * KLD + 4 * u); MIVOS_SB
+        MIVOS_MF0(u, 1)
+        MIVOS_MF1(u, 1)
+        if (ABL != 1) slice_b(u);
+        MIVOS_SB
+        MIVOS_MF0(u, 2)
+        MIVOS_MF1(u, 2)
+        MIVOS_MF0(u, 3)
+        MIVOS_MF1(u, 3)
       }
-#undef MIVOS_MF
-      if (ABL == 1 && t >= 2) {                        // keep the MFMA results alive without selecting
+#undef MIVOS_MF0
+#undef MIVOS_MF1
+#undef MIVOS_SB
+      if (ABL == 1 && t >= 2) {                 // keep the MFMA results alive without selecting
         const float sum = (acc0.x + acc0.y) + (acc1.z + acc1.w);
         if (sum == 123.456f) my_tau = sum;
       } else {
-        p0 = acc0; p1 = acc1;
-        pb = r0 + t * KT;
+        latch_scores(acc0, acc1, t);
       }
       __syncthreads();
     };
@@ -356,9 +397,10 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
       if (t + 1 < nt) tile_iter(t + 1, fb0, fb1, fa0, fa1, krB);
     }
     // drain the pipeline: select on the last tile
+    const unsigned long long cfin = prof ? __builtin_readcyclecounter() : 0ull;
     make_room();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { slice_a(i); slice_b(i); slice_c(); }
+    for (int i = 0; i < 8; ++i) { slice_a(i); slice_b(i); }
 
     // this segment's candidate lists: for each of the wave's 16 queries between min(n, k) and k + SLACK entries
     for (int ql = 0; ql < QW; ++ql) {
@@ -370,19 +412,29 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
       const uint64_t *src = cand + (wave * 4 * QW + ql) * REG;     // region g at src + g * QW * REG
       uint64_t *dst = a.lists + (((long long)stream * a.slots + slot) * QT + s) * a.L;
       // n0 + n1 + n2 + n3 <= k + SLACK = L <= 80: lanes 0..REG-1 copy one entry of each region, the rest is zero-filled
-      if (lane < n0) dst[lane] = src[lane];
-      if (lane < n1) dst[n0 + lane] = src[QW * REG + lane];
-      if (lane < n2) dst[n0 + n1 + lane] = src[2 * QW * REG + lane];
-      if (lane < n3) dst[n0 + n1 + n2 + lane] = src[3 * QW * REG + lane];
+      if (lane < n0) dst[lane] = raw_to_key(src[lane]);
+      if (lane < n1) dst[n0 + lane] = raw_to_key(src[QW * REG + lane]);
+      if (lane < n2) dst[n0 + n1 + lane] = raw_to_key(src[2 * QW * REG + lane]);
+      if (lane < n3) dst[n0 + n1 + n2 + lane] = raw_to_key(src[3 * QW * REG + lane]);
       for (int i = n0 + n1 + n2 + n3 + lane; i < a.L; i += 64) dst[i] = 0ull;
     }
+    if (prof) clk_final += __builtin_readcyclecounter() - cfin;
     t_begin += nt;
   }
-  if (a.dbg && blockIdx.x == 0 && tid == 0) {
+  if (prof && tid == 0) {
     a.dbg[0] = __builtin_readcyclecounter() - clk0;
     a.dbg[1] = (unsigned long long)(t_end - (long long)blockIdx.x * a.tiles_per_wg);
+    a.dbg[2] = clk_room; a.dbg[3] = n_compact; a.dbg[4] = clk_final; a.dbg[5] = clk_pro;
   }
 }
+
+// optional SH32 outputs of the readout (zero-bordered activation buffers of the LDS-DMA convolutions): raw and relu(raw),
+// addressed as image `obj`, pixel (q / q_width, q % q_width); strides in floats
+struct ShOut {
+  float *raw, *relu;
+  long long ns, rs, ps;
+  int q_width;
+};
 
 // one single-wave workgroup per (object, query); __syncthreads() on a 64-thread block is just the LDS ordering fence
 // between the phases
@@ -392,7 +444,7 @@ __global__ __launch_bounds__(64) void memread_finalize_kernel(const uint64_t *__
                                                              float *__restrict__ out, long long out_ostride,
                                                              long long out_pstride, int32_t *__restrict__ idx_out,
                                                              float *__restrict__ w_out, int n_q, int top_k, int n_qtiles,
-                                                             int tps, int tiles_per_wg, int slots, int L) {
+                                                             int tps, int tiles_per_wg, int slots, int L, ShOut sh) {
   __shared__ uint64_t sel[MAX_TOPK];
   __shared__ float wv[MAX_TOPK];
   __shared__ uint32_t oi[MAX_TOPK];
@@ -474,9 +526,20 @@ __global__ __launch_bounds__(64) void memread_finalize_kernel(const uint64_t *__
     a0.x = fmaf(wt, v0.x, a0.x); a0.y = fmaf(wt, v0.y, a0.y); a0.z = fmaf(wt, v0.z, a0.z); a0.w = fmaf(wt, v0.w, a0.w);
     a1.x = fmaf(wt, v1.x, a1.x); a1.y = fmaf(wt, v1.y, a1.y); a1.z = fmaf(wt, v1.z, a1.z); a1.w = fmaf(wt, v1.w, a1.w);
   }
-  float *o = out + (long long)obj * out_ostride + (long long)q * out_pstride + 4 * lane;
-  *reinterpret_cast<f32x4 *>(o) = a0;
-  *reinterpret_cast<f32x4 *>(o + 256) = a1;
+  if (out) {
+    float *o = out + (long long)obj * out_ostride + (long long)q * out_pstride + 4 * lane;
+    *reinterpret_cast<f32x4 *>(o) = a0;
+    *reinterpret_cast<f32x4 *>(o + 256) = a1;
+  }
+  if (sh.raw || sh.relu) {      // the decoder's first convolutions read the readout pre-split (and through ReLU): no pack pass
+    const int qy = q / sh.q_width, qx = q - qy * sh.q_width;
+    const long long pix = (long long)obj * sh.ns + (long long)qy * sh.rs + (long long)qx * sh.ps;
+    if (sh.raw) { store_sh32x4(sh.raw, pix, 4 * lane, a0); store_sh32x4(sh.raw, pix, 256 + 4 * lane, a1); }
+    if (sh.relu) {
+      store_sh32x4(sh.relu, pix, 4 * lane, f32x4{fmaxf(a0.x, 0.f), fmaxf(a0.y, 0.f), fmaxf(a0.z, 0.f), fmaxf(a0.w, 0.f)});
+      store_sh32x4(sh.relu, pix, 256 + 4 * lane, f32x4{fmaxf(a1.x, 0.f), fmaxf(a1.y, 0.f), fmaxf(a1.z, 0.f), fmaxf(a1.w, 0.f)});
+    }
+  }
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------
@@ -530,19 +593,19 @@ static int check_select_args(const float *keys, int64_t keys_ostride, const floa
 
 template <bool INDICES, int N>
 static void launch_finalize_n(const Plan &pl, void *workspace, const float *values, int64_t values_ostride, float *out, int64_t out_ostride,
-                              int64_t out_pstride, int32_t *idx_out, float *w_out, int n_obj, int n_q, int top_k, hipStream_t st) {
+                              int64_t out_pstride, int32_t *idx_out, float *w_out, int n_obj, int n_q, int top_k, hipStream_t st, const ShOut &sh) {
   hipLaunchKernelGGL((memread_finalize_kernel<INDICES, N>), dim3(n_q, n_obj), dim3(64), 0, st, (const uint64_t *)workspace, values,
                      (long long)values_ostride, out, (long long)out_ostride, (long long)out_pstride, idx_out, w_out, n_q, top_k,
-                     pl.n_qtiles, pl.tps, pl.tiles_per_wg, pl.slots, pl.L);
+                     pl.n_qtiles, pl.tps, pl.tiles_per_wg, pl.slots, pl.L, sh);
 }
 
 static int launch_finalize(bool indices, const Plan &pl, void *workspace, const float *values, int64_t values_ostride, float *out,
                            int64_t out_ostride, int64_t out_pstride, int32_t *idx_out, float *w_out, int n_obj, int n_q, int top_k,
-                           hipStream_t st) {
+                           hipStream_t st, const ShOut &sh = ShOut{nullptr, nullptr, 0, 0, 0, 1}) {
   const int per_lane = cdiv((long long)pl.slots * pl.L, 64);       // slots bounds the segments of any stream
 #define MIVOS_FIN(N)                                                                                                              \
-  (indices ? launch_finalize_n<true, N>(pl, workspace, values, values_ostride, out, out_ostride, out_pstride, idx_out, w_out, n_obj, n_q, top_k, st) \
-           : launch_finalize_n<false, N>(pl, workspace, values, values_ostride, out, out_ostride, out_pstride, idx_out, w_out, n_obj, n_q, top_k, st))
+  (indices ? launch_finalize_n<true, N>(pl, workspace, values, values_ostride, out, out_ostride, out_pstride, idx_out, w_out, n_obj, n_q, top_k, st, sh) \
+           : launch_finalize_n<false, N>(pl, workspace, values, values_ostride, out, out_ostride, out_pstride, idx_out, w_out, n_obj, n_q, top_k, st, sh))
   if (per_lane <= 4) MIVOS_FIN(4);
   else if (per_lane <= 8) MIVOS_FIN(8);
   else MIVOS_FIN(FIN_EPL_MAX);
@@ -580,7 +643,7 @@ extern "C" int mivos_memory_read_select(const float *keys, int64_t keys_ostride,
   static unsigned long long *dbg_buf = nullptr;
   a.dbg = nullptr;
   if (dbg) {
-    if (!dbg_buf && hipMalloc((void **)&dbg_buf, 16) != hipSuccess) dbg_buf = nullptr;
+    if (!dbg_buf && hipMalloc((void **)&dbg_buf, 64) != hipSuccess) dbg_buf = nullptr;
     a.dbg = dbg_buf;
   }
   if (abl == 1)
@@ -588,11 +651,12 @@ extern "C" int mivos_memory_read_select(const float *keys, int64_t keys_ostride,
   else
     hipLaunchKernelGGL(memread_select_kernel<0>, dim3(pl.n_wg), dim3(256), 0, (hipStream_t)stream, a);
   if (dbg && dbg_buf) {
-    unsigned long long h[2] = {0, 0};
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipStreamSynchronize((hipStream_t)stream);
-    hipMemcpy(h, dbg_buf, 16, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[memread_select] n_obj=%d n_mem=%lld n_q=%d: workgroup 0 ran %llu tiles in %llu shader-clock ticks = %.0f per tile (ideal 2048 MFMA cycles)\n",
-            n_obj, (long long)n_mem, n_q, h[1], h[0], h[1] ? (double)h[0] / (double)h[1] : 0.0);
+    hipMemcpy(h, dbg_buf, 48, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[memread_select] n_obj=%d n_mem=%lld n_q=%d: workgroup 0 ran %llu tiles in %llu shader-clock ticks = %.0f per tile (ideal 2048 MFMA cycles); "
+            "wave 0: %llu compactions in the loop = %llu ticks, segment prologues %llu, drains + final lists %llu\n",
+            n_obj, (long long)n_mem, n_q, h[1], h[0], h[1] ? (double)h[0] / (double)h[1] : 0.0, h[3], h[2], h[5], h[4]);
   }
   return check_launch("memread_select");
 }
@@ -607,6 +671,19 @@ extern "C" int mivos_memory_read_finalize(const float *values, int64_t values_os
   const Plan pl = make_plan(n_obj, n_mem, n_q, top_k);
   return launch_finalize(false, pl, workspace, values, values_ostride, out, out_ostride, out_pstride, nullptr, nullptr, n_obj, n_q,
                          top_k, (hipStream_t)stream);
+}
+
+extern "C" int mivos_memory_read_finalize_sh32(const float *values, int64_t values_ostride, void *raw_sh32, void *relu_sh32,
+                                               int64_t a_nstride, int64_t a_rstride, int64_t a_pstride, int q_width, int n_obj,
+                                               int64_t n_mem, int n_q, int top_k, void *workspace, int64_t workspace_bytes, void *stream) {
+  if (!values || !workspace || (!raw_sh32 && !relu_sh32) || ((uintptr_t)values & 15) || (values_ostride & 3) || q_width < 1 || n_q % q_width ||
+      ((a_nstride | a_rstride | a_pstride) & 31) || ((uintptr_t)raw_sh32 & 127) || ((uintptr_t)relu_sh32 & 127))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read_finalize_sh32: bad arguments");
+  if (top_k < 1 || top_k > MAX_TOPK || n_mem < top_k || workspace_bytes < mivos_memory_read_workspace_bytes(n_obj, n_mem, n_q, top_k))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read_finalize_sh32: arguments do not match the select call");
+  const Plan pl = make_plan(n_obj, n_mem, n_q, top_k);
+  const ShOut sh{(float *)raw_sh32, (float *)relu_sh32, a_nstride, a_rstride, a_pstride, q_width};
+  return launch_finalize(false, pl, workspace, values, values_ostride, nullptr, 0, 0, nullptr, nullptr, n_obj, n_q, top_k, (hipStream_t)stream, sh);
 }
 
 extern "C" int mivos_memory_read_topk(const float *keys, int64_t keys_ostride, const float *values, int64_t values_ostride,

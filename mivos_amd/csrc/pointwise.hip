@@ -4,7 +4,7 @@
 #include <stdarg.h>
 #include <string.h>
 
-#include "common.h"
+#include "conv_common.h"
 
 namespace mivos {
 
@@ -88,6 +88,90 @@ __global__ void upsample2x_add_kernel(const float *__restrict__ skip, int64_t sk
     o.z = s.z + (hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z));
     o.w = s.w + (hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w));
     reinterpret_cast<f32x4 *>(out)[i] = o;
+  }
+}
+
+// The same with up to three outputs that feed the next layers without a conversion pass: dense fp32, SH32 (the pre-split
+// activation format of the LDS-DMA convolutions, written into the interior of a zero-bordered buffer) and SH32 of relu(x)
+// (pre-activation ResBlocks: the DMA-staged operand cannot be modified on load, so its producer applies the ReLU).
+__global__ void upsample2x_add_multi_kernel(const float *__restrict__ skip, int64_t skip_ns, const float *__restrict__ up,
+                                            float *__restrict__ out, float *__restrict__ raw, float *__restrict__ rel, int64_t a_ns,
+                                            int64_t a_rs, int64_t a_ps, int N, int h, int w, int C4) {
+  const int H = 2 * h, W = 2 * w;
+  const int64_t total = (int64_t)N * H * W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    int64_t t = i / C4;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilin_coord(y, 0.5f, h, y0, y1, ly);
+    bilin_coord(x, 0.5f, w, x0, x1, lx);
+    const f32x4 *u = reinterpret_cast<const f32x4 *>(up) + (int64_t)n * h * w * C4 + c;
+    const f32x4 v00 = u[((int64_t)y0 * w + x0) * C4], v01 = u[((int64_t)y0 * w + x1) * C4];
+    const f32x4 v10 = u[((int64_t)y1 * w + x0) * C4], v11 = u[((int64_t)y1 * w + x1) * C4];
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const f32x4 s = reinterpret_cast<const f32x4 *>(skip + (int64_t)n * skip_ns)[((int64_t)y * W + x) * C4 + c];
+    f32x4 o;
+    o.x = s.x + (hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x));
+    o.y = s.y + (hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y));
+    o.z = s.z + (hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z));
+    o.w = s.w + (hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w));
+    if (out) reinterpret_cast<f32x4 *>(out)[i] = o;
+    const long long pix = (long long)n * a_ns + (long long)y * a_rs + (long long)x * a_ps;
+    if (raw) store_sh32x4(raw, pix, 4 * c, o);
+    if (rel) store_sh32x4(rel, pix, 4 * c, f32x4{fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f)});
+  }
+}
+
+// MaxPool 3x3 / 2 / pad 1 writing SH32 into the interior of a zero-bordered buffer (the ResNet stem's output feeds stage 1)
+__global__ void maxpool3x3s2_sh32_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t a_ns, int64_t a_rs, int64_t a_ps,
+                                         int N, int H, int W, int C4, int Ho, int Wo) {
+  const int64_t total = (int64_t)N * Ho * Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    int64_t t = i / C4;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int ih = oh * 2 - 1 + dy;
+      if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int iw = ow * 2 - 1 + dx;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const f32x4 v = reinterpret_cast<const f32x4 *>(x)[(((int64_t)n * H + ih) * W + iw) * C4 + c];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    store_sh32x4(y, (long long)n * a_ns + (long long)oh * a_rs + (long long)ow * a_ps, 4 * c, m);
+  }
+}
+
+// 3x3 / pad 1 convolution with ONE output channel, second half: t holds, per input pixel, the nine tap products
+// t[p][k] = w[k] . x[p] (a 1x1 projection to 16 channels computed by the GEMM kernels, which read x exactly once);
+// out[y][x] = bias + sum_k t[y + k/3 - 1][x + k%3 - 1][k], zero outside the image.
+__global__ void tap_sum9_kernel(const float *__restrict__ t, const float *__restrict__ bias, float *__restrict__ out, int N, int H, int W) {
+  const int64_t total = (int64_t)N * H * W;
+  const float b = bias ? bias[0] : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    int64_t r = i / W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    const float *tn = t + (int64_t)n * H * W * 16;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) acc += tn[((int64_t)yy * W + xx) * 16 + k];
+    }
+    out[i] = acc + b;
   }
 }
 
@@ -292,6 +376,33 @@ extern "C" int mivos_upsample2x_add(const float *skip, int64_t skip_nstride, con
   if (!skip || !up || !out || C % 4 || (skip_nstride & 3)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "upsample2x_add: bad arguments");
   hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid_for((int64_t)N * 4 * h * w * (C / 4))), dim3(256), 0, ST, skip, skip_nstride, up, out, N, h, w, C / 4);
   return check_launch("upsample2x_add");
+}
+
+extern "C" int mivos_upsample2x_add_multi(const float *skip, int64_t skip_nstride, const float *up, float *out, void *raw_sh32,
+                                          void *relu_sh32, int64_t a_nstride, int64_t a_rstride, int64_t a_pstride, int N, int h, int w,
+                                          int C, void *stream) {
+  if (!skip || !up || (!out && !raw_sh32 && !relu_sh32) || C % 4 || (skip_nstride & 3)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "upsample2x_add_multi: bad arguments");
+  if ((raw_sh32 || relu_sh32) && ((C & 31) || ((a_nstride | a_rstride | a_pstride) & 31) || ((uintptr_t)raw_sh32 & 127) || ((uintptr_t)relu_sh32 & 127)))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "upsample2x_add_multi: SH32 outputs need C %% 32 == 0 and 128-byte aligned pixels");
+  hipLaunchKernelGGL(upsample2x_add_multi_kernel, dim3(grid_for((int64_t)N * 4 * h * w * (C / 4))), dim3(256), 0, ST, skip, skip_nstride, up, out,
+                     (float *)raw_sh32, (float *)relu_sh32, a_nstride, a_rstride, a_pstride, N, h, w, C / 4);
+  return check_launch("upsample2x_add_multi");
+}
+
+extern "C" int mivos_maxpool3x3s2_sh32(const float *x, void *y_sh32, int64_t y_nstride, int64_t y_rstride, int64_t y_pstride, int N, int H,
+                                       int W, int C, void *stream) {
+  if (!x || !y_sh32 || (C & 31) || N < 1 || ((y_nstride | y_rstride | y_pstride) & 31) || ((uintptr_t)y_sh32 & 127))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "maxpool3x3s2_sh32: bad arguments (C %% 32 != 0?)");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_sh32_kernel, dim3(grid_for((int64_t)N * Ho * Wo * (C / 4))), dim3(256), 0, ST, x, (float *)y_sh32, y_nstride,
+                     y_rstride, y_pstride, N, H, W, C / 4, Ho, Wo);
+  return check_launch("maxpool3x3s2_sh32");
+}
+
+extern "C" int mivos_tap_sum9(const float *t, const float *bias, float *out, int N, int H, int W, void *stream) {
+  if (!t || !out || N < 1 || H < 1 || W < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "tap_sum9: bad arguments");
+  hipLaunchKernelGGL(tap_sum9_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 0, ST, t, bias, out, N, H, W);
+  return check_launch("tap_sum9");
 }
 
 extern "C" int mivos_area_pool16(const float *x, float *y, int planes, int H, int W, void *stream) {

@@ -116,9 +116,8 @@ def run_trunk(plan, x, keep=True):
     kernels and the features are ops.Act (SH32, zero-bordered); keep=False puts them into scratch storage too (the
     caller consumes them before the next trunk call)."""
     stem, stages = plan
-    x = ops.maxpool3x3s2(ops.conv(x, stem, relu_out=True))
-    if ops.act_path():
-        x = ops.to_act(x, tag="trunk.stem")
+    x = ops.conv(x, stem, relu_out=True)
+    x = ops.maxpool3x3s2(x, act_tag="trunk.stem", as_act=True) if ops.act_path() else ops.maxpool3x3s2(x)   # SH32 from the pool itself
     feats = []
     for stage in stages:
         for i, blk in enumerate(stage):
@@ -182,6 +181,16 @@ def run_resblock(plan, x):
     return ops.conv(r, c2, relu_in=True, res=skip)
 
 
+def run_resblock_acts(plan, raw, rel, res1=None, res_skip=None):
+    """The same block on pre-split operands: `raw` / `rel` are SH32 Acts of x and relu(x) written by x's producer.
+    res1 / res_skip: partial sums (fp32, batch 1, broadcast) added to conv1 / to the skip convolution - the contribution of
+    input channels that are identical for every object and were convolved once (Decoder.compress, see prop_net.segment)."""
+    c1, c2, ds = plan
+    r = ops.conv(rel, c1, relu_out=True, res=res1, out_act=True, tag="resblock.mid")
+    skip = raw if ds is None else ops.conv(raw, ds, res=res_skip)
+    return ops.conv(r, c2, res=skip)
+
+
 class UpsampleBlock(nn.Module):
     """modules.py:92-104."""
 
@@ -202,6 +211,10 @@ def run_skip_branch(plan, skip_f):
     return run_resblock(sc2, ops.conv(skip_f, sc1))
 
 
-def run_up_branch(plan, skip_feat, up_f):
-    """out_conv(skip_feat + bilinear_x2(up_f)); skip_feat is broadcast over the object batch."""
+def run_up_branch(plan, skip_feat, up_f, tag="up"):
+    """out_conv(skip_feat + bilinear_x2(up_f)); skip_feat is broadcast over the object batch.  On the LDS-DMA path the
+    upsample kernel writes the sum pre-split, as x and as relu(x): no conversion pass before the ResBlock."""
+    if ops.act_path() and up_f.shape[3] % 32 == 0:
+        raw, rel = ops.upsample2x_add_acts(skip_feat, up_f, tag)
+        return run_resblock_acts(plan[2], raw, rel)
     return run_resblock(plan[2], ops.upsample2x_add(skip_feat, up_f))

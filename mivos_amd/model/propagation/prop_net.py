@@ -18,7 +18,7 @@ import torch.nn as nn
 from ... import ops
 from ..._lib import MivosHipError
 from .modules import (ConvParams, KeyValue, MaskRGBEncoder, ResBlock, RGBEncoder, UpsampleBlock,
-                      run_resblock, run_skip_branch, run_trunk, run_up_branch)
+                      run_resblock, run_resblock_acts, run_skip_branch, run_trunk, run_up_branch)
 
 CK, CV = 128, 512
 
@@ -34,7 +34,14 @@ class Decoder(nn.Module):
         self.pred = ConvParams(256, 1, 3, padding=1)
 
     def compile(self):
-        return dict(compress=self.compress.compile(), up_16_8=self.up_16_8.compile(),
+        c1, c2, ds = self.compress.compile()
+        # compress reads cat([memory readout (512, per object), v16 (512, the SAME for every object)]) (prop_net.py:178-179):
+        # a convolution over concatenated channels is the sum of the convolutions over the parts, so the v16 half is
+        # convolved once per frame (batch 1, cached with the query features) and added as a broadcast partial sum
+        half = c1.cin // 2
+        split = dict(c1m=c1.slice_cin(0, half, False), c1v=c1.slice_cin(half, c1.cin, True),
+                     dsm=ds.slice_cin(0, half, False), dsv=ds.slice_cin(half, ds.cin, True), c2=c2)
+        return dict(compress=(c1, c2, ds), compress_split=split, up_16_8=self.up_16_8.compile(),
                     up_8_4=self.up_8_4.compile(), pred=self.pred.pack())
 
 
@@ -77,11 +84,12 @@ class AttentionMemory(nn.Module):
 class QueryFeatures:
     """Per-frame query features, NHWC.  s8 / s4 (decoder skip branches, object independent) are
     filled lazily by PropagationNetwork._skip()."""
-    __slots__ = ("f16", "f8", "f4", "k16", "v16", "s8", "s4")
+    __slots__ = ("f16", "f8", "f4", "k16", "v16", "s8", "s4", "c1v", "dsv")
 
     def __init__(self, f16, f8, f4, k16, v16):
         self.f16, self.f8, self.f4, self.k16, self.v16 = f16, f8, f4, k16, v16
         self.s8 = self.s4 = None
+        self.c1v = self.dsv = None        # object-independent partial sums of Decoder.compress (the v16 half of its input)
 
     def as_reference_tuple(self):
         dense = [ops.to_f32(t) if isinstance(t, ops.Act) else t for t in (self.f16, self.f8, self.f4, self.k16, self.v16)]
@@ -183,23 +191,35 @@ class PropagationNetwork(nn.Module):
         x = ops.interleave([(flat[c * P:], 3 * P) for c in range(3)], B, P, 4, frames.device).view(B, H, W, 4)
         f16, f8, f4 = run_trunk(p["qenc"], x)
         k16, v16 = ops.conv(f16, p["kv_q"])
-        s8 = s4 = None
+        s8 = s4 = c1v = dsv = None
         if with_skip:
             s8 = run_skip_branch(p["dec"]["up_16_8"], f8)
             s4 = run_skip_branch(p["dec"]["up_8_4"], f4)
+            if ops.act_path():
+                c1v, dsv = self._compress_v16(p["dec"]["compress_split"], v16)
         out = []
         for b in range(B):
             q = QueryFeatures(f16[b:b + 1], f8[b:b + 1], f4[b:b + 1], k16[b:b + 1], v16[b:b + 1])
             if with_skip:
                 q.s8, q.s4 = s8[b:b + 1], s4[b:b + 1]
+                if c1v is not None:
+                    q.c1v, q.dsv = c1v[b:b + 1], dsv[b:b + 1]
             out.append(q)
         return out
 
+    @staticmethod
+    def _compress_v16(cs, v16):
+        """The v16 half of Decoder.compress's two input convolutions (conv1 on relu(v16), the skip conv on v16), bias
+        included: [B,h,w,512] fp32 each, identical for every object of the frame."""
+        return (ops.conv(ops.to_act(v16, relu=True, tag="v16.relu"), cs["c1v"]), ops.conv(ops.to_act(v16, tag="v16.raw"), cs["dsv"]))
+
     def _skip(self, q):
+        dec = self.plan()["dec"]
         if q.s8 is None:
-            dec = self.plan()["dec"]
             q.s8 = run_skip_branch(dec["up_16_8"], q.f8)
             q.s4 = run_skip_branch(dec["up_8_4"], q.f4)
+        if q.c1v is None and ops.act_path():
+            q.c1v, q.dsv = self._compress_v16(dec["compress_split"], q.v16)
         return q.s8, q.s4
 
     def memorize_into(self, frame, masks, key_out=None, val_out=None):
@@ -238,12 +258,19 @@ class PropagationNetwork(nn.Module):
         if K > cap:
             return torch.cat([self.segment(keys[i:i + cap], values[i:i + cap], q, logits) for i in range(0, K, cap)], 0)
         s8, s4 = self._skip(q)
-        m4 = torch.empty((K, h, w, 2 * CV), dtype=torch.float32, device=keys.device)
-        ops.memory_read(keys, values, q.k16.view(h * w, CK), self.memory.top_k, out=m4.view(K, h * w, 2 * CV)[:, :, :CV])
-        m4[..., CV:] = q.v16                                            # cat([mem, v16.expand(K)]) (prop_net.py:178-179)
-        x = run_resblock(dec["compress"], m4)
-        x = run_up_branch(dec["up_16_8"], s8, x)
-        x = run_up_branch(dec["up_8_4"], s4, x)
+        if ops.act_path():
+            # the readout lands pre-split (x and relu(x)) in the compress block's input buffers; the v16 half of
+            # cat([mem, v16.expand(K)]) (prop_net.py:178-179) enters as the cached partial sums q.c1v / q.dsv
+            raw, rel = ops.memory_read_acts(keys, values, q.k16.reshape(h * w, CK), self.memory.top_k, h, w)
+            cs = dec["compress_split"]
+            x = run_resblock_acts((cs["c1m"], cs["c2"], cs["dsm"]), raw, rel, res1=q.c1v, res_skip=q.dsv)
+        else:
+            m4 = torch.empty((K, h, w, 2 * CV), dtype=torch.float32, device=keys.device)
+            ops.memory_read(keys, values, q.k16.reshape(h * w, CK), self.memory.top_k, out=m4.view(K, h * w, 2 * CV)[:, :, :CV])
+            m4[..., CV:] = q.v16                                        # cat([mem, v16.expand(K)]) (prop_net.py:178-179)
+            x = run_resblock(dec["compress"], m4)
+        x = run_up_branch(dec["up_16_8"], s8, x, tag="up16")
+        x = run_up_branch(dec["up_8_4"], s4, x, tag="up8")
         lo = ops.conv(x, dec["pred"], relu_in=True)                     # [K, H/4, W/4, 1]
         return ops.resize_bilinear(lo.view(K, lo.shape[1], lo.shape[2]), 4 * lo.shape[1], 4 * lo.shape[2],
                                    act=0 if logits else 1)

@@ -77,7 +77,7 @@ def _nhwc_strides(t):
 
 class ConvLayer:
     """Device-resident packed convolution: OHWI weights (+ folded BN scale / bias)."""
-    __slots__ = ("w", "scale", "bias", "cin", "cout", "k", "stride", "pad", "split", "w16", "scale16", "wdma")
+    __slots__ = ("w", "scale", "bias", "cin", "cout", "k", "stride", "pad", "split", "w16", "scale16", "wdma", "proj")
 
     def __init__(self, w_ohwi, scale, bias, stride, pad, split=None):
         self.w = w_ohwi.contiguous()
@@ -85,7 +85,23 @@ class ConvLayer:
         self.scale, self.bias = scale, bias
         self.stride, self.pad = stride, pad
         self.split = self.cout if split is None else split
-        self.w16 = self.scale16 = self.wdma = None
+        self.w16 = self.scale16 = self.wdma = self.proj = None
+
+    def projection(self):
+        """A 3x3 / pad 1 layer with ONE output channel as a 1x1 layer with 16 outputs, row k = the weights of tap k
+        (9 real rows): the GEMM kernels then read the input once and `tap_sum9` adds the nine shifted products."""
+        if self.proj is None:
+            assert self.cout == 1 and self.k == 3 and self.scale is None
+            w = self.w.new_zeros((16, 1, 1, self.cin))
+            w[:9, 0, 0] = self.w[0].reshape(9, self.cin)
+            self.proj = ConvLayer(w, None, None, 1, 0)
+        return self.proj
+
+    def slice_cin(self, c0, c1, keep_bias):
+        """The same layer restricted to input channels [c0, c1) (a convolution over concatenated inputs is the sum of the
+        convolutions over the parts; the bias / BN shift goes with one part)."""
+        assert self.scale is None
+        return ConvLayer(self.w[..., c0:c1].contiguous(), None, self.bias if keep_bias else None, self.stride, self.pad)
 
     def _f16x3_scale(self):
         """(2^s, scale * 2^-s): the exact power-of-two pre-scaling of the fp16 hi/lo weight split."""
@@ -153,7 +169,7 @@ class ConvLayer:
             v = getattr(self, n)
             if v is not None:
                 setattr(self, n, v.to(device))
-        self.w16 = self.scale16 = self.wdma = None
+        self.w16 = self.scale16 = self.wdma = self.proj = None
         return self
 
 
@@ -254,6 +270,16 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
         raise MivosHipError("conv: an Act input needs the f16x3 back-end, Cout > 1 and relu applied by its producer")
     if out_act and not from_act:
         raise MivosHipError("conv: SH32 outputs are written by the LDS-DMA kernels only (Act input)")
+    if (L.cout == 1 and L.k == 3 and L.stride == 1 and L.pad == 1 and L.scale is None and CONV_PRECISION == "f16x3"
+            and not from_act and res is None and not relu_out and cin % 32 == 0):
+        # one output channel: 1x1 projection to the nine tap products (reads x once) + 9-point sum, instead of a dot-product
+        # kernel that re-reads every pixel for each of its nine neighbours
+        t = conv(x, L.projection(), relu_in=relu_in)
+        if out is None:
+            out = torch.empty((n, h, w, 1), dtype=torch.float32, device=dev)
+        assert out.is_contiguous() and out.numel() == n * h * w
+        check(_lib.load().mivos_tap_sum9(t.data_ptr(), L.bias.data_ptr() if L.bias is not None else None, out.data_ptr(), n, h, w, _stream()))
+        return out
     ho = (h + 2 * L.pad - L.k) // L.stride + 1
     wo = (w + 2 * L.pad - L.k) // L.stride + 1
     dual = L.split < L.cout
@@ -321,13 +347,34 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
     return (out, out2) if dual else out
 
 
-def maxpool3x3s2(x):
+def maxpool3x3s2(x, act_tag=None, as_act=False):
+    """MaxPool 3x3 / 2 / pad 1.  as_act=True writes the result straight into an SH32 Act (scratch `act_tag`)."""
     _ensure_device(x)
     n, h, w, c = x.shape
     assert x.is_contiguous()
-    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if as_act:
+        a = alloc_act(n, ho, wo, c, x.device, act_tag)
+        an, ar, ap = a.strides()
+        check(_lib.load().mivos_maxpool3x3s2_sh32(x.data_ptr(), a.interior_ptr(), an, ar, ap, n, h, w, c, _stream()))
+        return a
+    y = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
     check(_lib.load().mivos_maxpool3x3s2(x.data_ptr(), y.data_ptr(), n, h, w, c, _stream()))
     return y
+
+
+def upsample2x_add_acts(skip, up, tag):
+    """skip [1 or N, 2h, 2w, C] + bilinear_x2(up [N, h, w, C]) -> (SH32 Act of the sum, SH32 Act of its ReLU), scratch
+    buffers `tag`: the two operands a pre-activation ResBlock reads (raw for its skip path, relu for conv1)."""
+    _ensure_device(up)
+    n, h, w, c = up.shape
+    assert up.is_contiguous() and skip.is_contiguous() and skip.shape[1:] == (2 * h, 2 * w, c)
+    raw, rel = alloc_act(n, 2 * h, 2 * w, c, up.device, (tag, "raw")), alloc_act(n, 2 * h, 2 * w, c, up.device, (tag, "relu"))
+    sn = 0 if (skip.shape[0] == 1 and n > 1) else skip.stride(0)
+    an, ar, ap = raw.strides()
+    check(_lib.load().mivos_upsample2x_add_multi(skip.data_ptr(), sn, up.data_ptr(), None, raw.interior_ptr(), rel.interior_ptr(), an, ar, ap,
+                                                 n, h, w, c, _stream()))
+    return raw, rel
 
 
 def upsample2x_add(skip, up):
@@ -395,6 +442,38 @@ def memory_read(keys, values, qk, top_k, out=None):
     PROFILE.append((90, 2.0 * k * n_mem * n_q * 128, ev[0], ev[1], (k, n_mem, n_q, top_k, 4.0 * 128 * (k * n_mem + n_q))))
     PROFILE.append((91, 2.0 * k * n_q * top_k * 512, ev[2], ev[3], (k, n_mem, n_q, top_k, 4.0 * 512 * k * n_q * (top_k + 1))))
     return out
+
+
+def memory_read_acts(keys, values, qk, top_k, h, w, tag="memread"):
+    """memory_read whose readout lands pre-split in two SH32 Acts [K, h, w, 512]: (raw, relu(raw)) - what the decoder's first
+    ResBlock reads.  keys [K, n_mem, 128], values [K, n_mem, 512], qk [h*w, 128]."""
+    _ensure_device(keys)
+    keys, ko = _rows(_f32(keys), 128)
+    values, vo = _rows(_f32(values), 512)
+    k, n_mem, _ = keys.shape
+    n_q = qk.shape[0]
+    assert qk.is_contiguous() and qk.shape[1] == 128 and values.shape[:2] == (k, n_mem) and n_q == h * w
+    if top_k is None:
+        raise MivosHipError("memory_read: top_k=None (full softmax) is not part of the propagation path")
+    raw, rel = alloc_act(k, h, w, 512, keys.device, (tag, "raw")), alloc_act(k, h, w, 512, keys.device, (tag, "relu"))
+    lib = _lib.load()
+    ws = _workspace(lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k), keys.device, "memread")
+    an, ar, ap = raw.strides()
+    ev = None
+    if PROFILE is not None:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+    check(lib.mivos_memory_read_select(keys.data_ptr(), ko, qk.data_ptr(), k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
+    if ev:
+        ev[1].record()
+        ev[2].record()
+    check(lib.mivos_memory_read_finalize_sh32(values.data_ptr(), vo, raw.interior_ptr(), rel.interior_ptr(), an, ar, ap, w, k, n_mem, n_q, top_k,
+                                              ws.data_ptr(), ws.numel(), _stream()))
+    if ev:
+        ev[3].record()
+        PROFILE.append((90, 2.0 * k * n_mem * n_q * 128, ev[0], ev[1], (k, n_mem, n_q, top_k, 4.0 * 128 * (k * n_mem + n_q))))
+        PROFILE.append((91, 2.0 * k * n_q * top_k * 512, ev[2], ev[3], (k, n_mem, n_q, top_k, 4.0 * 512 * k * n_q * (top_k + 2))))
+    return raw, rel
 
 
 def memory_read_indices(keys, qk, top_k):

@@ -18,6 +18,7 @@ CASES = [("480p K=1 T=5 top20", 1, 5, 1620, 20, 3.0), ("480p K=1 T=12 top20", 1,
          ("480p K=5 T=12 top50", 5, 12, 1620, 50, 3.0), ("480p K=5 T=12 top50 flat", 5, 12, 1620, 50, 1.0),
          ("480p K=3 T=12 top50", 3, 12, 1620, 50, 3.0),
          ("1080p K=3 T=20 top50", 3, 20, 8160, 50, 3.0), ("1080p K=3 T=100 top50", 3, 100, 8160, 50, 3.0)]
+torch.manual_seed(0)
 reps = 5
 lib = _lib.load()
 for name, K, T, hw, topk, scale in CASES:

@@ -171,8 +171,9 @@ def test_fusion_generator_call_pattern_vs_oracle(nets, synthetic_states):
         margin, O.TOPK_GAP = min(O.TOPK_GAP), None
         d = float((out.cpu() - ref).abs().max())
         print(f"frame {ti}: bank T={this_k.shape[2]}  max|dprob| {d:.2e}  top-k margin {margin:.1e}")
-        # a 20th/21st-neighbour tie inside fp32 rounding may legitimately resolve either way
-        assert d < (2.5e-4 if margin > 1e-4 else 2.5e-3)
+        # the bar is "logits within 1e-3"; the aggregated probability moves by at most half the logit error (softmax over the
+        # objects' logits).  A 20th/21st-neighbour tie inside fp32 rounding may legitimately resolve either way
+        assert d < (5e-4 if margin > 1e-4 else 2.5e-3)
         assert mean_iou(out.argmax(0).cpu().numpy(), ref.argmax(0).numpy(), 2) >= 0.999
         if ti != 4:
             prev = prop.memorize(images[:, ti].to(DEV), out[1:])
