@@ -91,6 +91,8 @@ typedef struct {
   int32_t x_format;    /* 0: fp32, 1: SH32 (must be 1 for precision 2, 0 otherwise)                             */
   int32_t y_format;    /* 0: fp32, 1: SH32 (channels [0, split) only; needs the 16-byte vectorised epilogue)   */
   int32_t res_format;  /* 0: fp32, 1: SH32                                                                      */
+  int32_t dilation;    /* spacing of the kernel taps (0 or 1: dense).  DeepLab's atrous convolutions (model/s2m/_deeplab.py:
+                          110-118, s2m_resnet.py:17-20) use 2 / 6 / 12 / 18 with pad == dilation; precision 0 / 1 only.       */
 } mivos_conv_desc;
 
 int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream);
@@ -264,6 +266,35 @@ typedef struct {
   int32_t C;
 } mivos_interleave_desc;
 int mivos_interleave_planes(const mivos_interleave_desc *d, float *out, int N, int64_t P, void *stream);
+
+/* ---- scribble-to-mask network (model/s2m: DeepLabV3+ / ResNet-50, the step before the path, davis_processor.py:38-70) ----
+ * Its convolutions run on mivos_conv2d_fused (dilation field); these are the remaining operators. */
+
+/* F.interpolate(mode='bilinear', align_corners=False) of an NHWC map [N][h][w][C] to H x W, written to
+ * y + n*y_nstride + (Y*W + X)*y_pstride + c (a channel slice of the concatenation buffer, _deeplab.py:48-49). */
+int mivos_resize_bilinear_nhwc(const float *x, float *y, int64_t y_nstride, int64_t y_pstride, int N, int h, int w, int H,
+                               int W, int C, void *stream);
+/* nn.AdaptiveAvgPool2d(1) on NHWC (ASPPPooling, _deeplab.py:120-131): x [N][P][C] -> y [N][C]. */
+int mivos_global_avgpool(const float *x, float *y, int N, int64_t P, int C, void *stream);
+/* cv2.dilate(mask, ones(3,3)) on binary float planes (davis_processor.py:55-60). */
+int mivos_dilate3x3(const float *x, float *y, int planes, int H, int W, void *stream);
+
+/* ---- clip ingest (the step before the path: dataset/davis_test_dataset.py:66-110, dataset/yv_test_dataset.py:54-119) ----
+ * Outputs are written with explicit plane / row strides and a (top, left) offset, i.e. straight into the interior of the
+ * zero-padded [1,T,3,nh,nw] tensor InferenceCore keeps (pad_divide_by, util/tensor_util.py:62-80). */
+
+/* Decoded frames [T][H][W][3] uint8 -> (float(u8)/255 - mean[c]) / std[c] (torchvision ToTensor + Normalize,
+ * dataset/range_transform.py:5-8; true divisions, bit-identical), channel c of frame t at out + t*out_tstride +
+ * c*out_cstride.  mean3 / std3 are HOST pointers. */
+int mivos_ingest_u8(const uint8_t *frames, float *out, int T, int H, int W, int64_t out_tstride, int64_t out_cstride,
+                    int64_t out_rstride, int pad_top, int pad_left, const float *mean3, const float *std3, void *stream);
+/* F.interpolate(mode='bicubic', align_corners=False) (yv_test_dataset.py:107): planes [P][h][w] -> [P][H][W]. */
+int mivos_resize_bicubic(const float *x, float *out, int planes, int h, int w, int H, int W, int64_t out_pstride,
+                         int64_t out_rstride, int pad_top, int pad_left, void *stream);
+/* Palette-index label map [h][w] uint8 -> one-hot float planes for labels[0..n_labels) (device pointer), resized with the
+ * 'nearest' rule of yv_test_dataset.py:108 (src = floor(dst * in / out)); dataset/onehot_util semantics. */
+int mivos_onehot_nearest(const uint8_t *label_map, const uint8_t *labels, int n_labels, float *out, int h, int w, int H,
+                         int W, int64_t out_pstride, int64_t out_rstride, int pad_top, int pad_left, void *stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
                 ("y2_nstride", i64), ("y2_pstride", i64), ("res_nstride", i64), ("res_pstride", i64),
                 ("workspace", vp), ("workspace_bytes", i64),
                 ("x_rstride", i64), ("y_rstride", i64), ("res_rstride", i64),
-                ("x_border", i32), ("x_format", i32), ("y_format", i32), ("res_format", i32)]
+                ("x_border", i32), ("x_format", i32), ("y_format", i32), ("res_format", i32), ("dilation", i32)]
 
 
 class InterleaveDesc(C.Structure):
@@ -68,6 +68,12 @@ PROTOTYPES = {
     "mivos_mask_diff": (C.c_int, [vp, vp, vp, vp, i64, vp]),
     "mivos_sigmoid": (C.c_int, [vp, vp, i64, vp]),
     "mivos_mask_others": (C.c_int, [vp, vp, C.c_int, i64, vp]),
+    "mivos_resize_bilinear_nhwc": (C.c_int, [vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_global_avgpool": (C.c_int, [vp, vp, C.c_int, i64, C.c_int, vp]),
+    "mivos_dilate3x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_ingest_u8": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, i64, i64, i64, C.c_int, C.c_int, C.POINTER(f32), C.POINTER(f32), vp]),
+    "mivos_resize_bicubic": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i64, i64, C.c_int, C.c_int, vp]),
+    "mivos_onehot_nearest": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, i64, i64, C.c_int, C.c_int, vp]),
     "mivos_interleave_planes": (C.c_int, [C.POINTER(InterleaveDesc), vp, C.c_int, i64, vp]),
 }
 

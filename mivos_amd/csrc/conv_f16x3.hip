@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvP p, int kpad4) 
     else { kh = tap / p.KW; kw = tap - p.KW * kh; }
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+      const int ih = a_ih0[j] + kh * p.dil, iw = a_iw0[j] + kw * p.dil;
       const bool ok = a_ok[j] && kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       f32x4 v = zero4;
       if (ok) v = *reinterpret_cast<const f32x4 *>(a_base[j] + ((long long)ih * p.W + iw) * p.x_ps + c);
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_pipe_kernel(ConvP p, int kpad4
     }
     if (s < A_LD) {
       const int j = s < A_LD ? s : 0;
-      const int ih = a_ih0[j] + ld_kh, iw = a_iw0[j] + ld_kw;
+      const int ih = a_ih0[j] + ld_kh * p.dil, iw = a_iw0[j] + ld_kw * p.dil;
       const bool ok = ld_kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       long long off = ok ? ((long long)ih * p.W + iw) * p.x_ps + ld_c : 0ll;
       if (ABL == 4) off = (off & 0xfff);          // all loads from one hot 16 KB window (cache-hit ablation)
@@ -895,7 +895,7 @@ int select_variant_f16x3(int M, int Cout) {
 }
 
 int launch_conv_f16x3(ConvP &p, hipStream_t st) {
-  if (p.vec_epi && p.Cout == 32 && p.split == 32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && (p.Cin == 16 || p.Cin == 32))
+  if (p.vec_epi && p.Cout == 32 && p.split == 32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 && (p.Cin == 16 || p.Cin == 32))
     return p.Cin == 16 ? launch_n32_direct<16>(p, st) : launch_n32_direct<32>(p, st);
   // direct 3x3 (LDS patch reuse) for wide stride-1 layers with enough 8x32 tiles to fill the chip
   // Measured equal to the pipelined implicit GEMM on the decoder shapes (302 vs 307 TFLOP/s) although it
@@ -903,7 +903,7 @@ int launch_conv_f16x3(ConvP &p, hipStream_t st) {
   // the GEMM today; kept selectable (MIVOS_DIRECT3X3_MIN_TILES=<n>, 0 forces it) for the next tuning round.
   const char *mt = getenv("MIVOS_DIRECT3X3_MIN_TILES");
   const long long min_tiles = mt ? atoll(mt) : (1ll << 60);
-  if (p.vec_epi && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && (p.Cin & 31) == 0 && p.Cout >= 224 &&
+  if (p.vec_epi && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 && (p.Cin & 31) == 0 && p.Cout >= 224 &&
       (long long)p.N * cdiv(p.H, 8) * cdiv(p.W, 32) * cdiv(p.Cout, 256) >= min_tiles)
     return launch_direct3x3<256>(p, st);
   switch (select_variant_f16x3(p.M, p.Cout)) {

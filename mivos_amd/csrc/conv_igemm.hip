@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     else { kh = tap / p.KW; kw = tap - p.KW * kh; }
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+      const int ih = a_ih0[j] + kh * p.dil, iw = a_iw0[j] + kw * p.dil;
       const bool ok = a_ok[j] && kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       f32x4 v = zero4;
       if (ok) v = *reinterpret_cast<const f32x4 *>(a_base[j] + ((long long)ih * p.W + iw) * p.x_ps + c);
@@ -162,10 +162,10 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvP p) {
   const float *xb = p.x + (long long)img * p.x_ns;
   float acc = 0.f;
   for (int kh = 0; kh < p.KH; ++kh) {
-    const int ih = oh * p.stride - p.pad + kh;
+    const int ih = oh * p.stride - p.pad + kh * p.dil;
     if ((unsigned)ih >= (unsigned)p.H) continue;
     for (int kw = 0; kw < p.KW; ++kw) {
-      const int iw = ow * p.stride - p.pad + kw;
+      const int iw = ow * p.stride - p.pad + kw * p.dil;
       if ((unsigned)iw >= (unsigned)p.W) continue;
       const f32x4 *px = reinterpret_cast<const f32x4 *>(xb + ((long long)ih * p.W + iw) * p.x_ps) + sub;
       const f32x4 *pw = reinterpret_cast<const f32x4 *>(wl + (kh * p.KW + kw) * p.Cin) + sub;
@@ -209,15 +209,17 @@ int conv_params_from_desc(const mivos_conv_desc *d, ConvP &p) {
   if (!d || !d->x || !d->w || !d->y) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: null pointer");
   if (d->Cin < 4 || (d->Cin & (d->Cin - 1))) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: Cin=%d must be a power of two >= 4", d->Cin);
   if (d->KH != d->KW || d->KH < 1 || d->stride < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: unsupported kernel %dx%d stride %d", d->KH, d->KW, d->stride);
-  if (d->Ho != (d->H + 2 * d->pad - d->KH) / d->stride + 1 || d->Wo != (d->W + 2 * d->pad - d->KW) / d->stride + 1)
-    return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: Ho/Wo inconsistent with H/W/pad/stride");
+  const int dil = d->dilation > 1 ? d->dilation : 1;
+  if (d->Ho != (d->H + 2 * d->pad - dil * (d->KH - 1) - 1) / d->stride + 1 || d->Wo != (d->W + 2 * d->pad - dil * (d->KW - 1) - 1) / d->stride + 1)
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: Ho/Wo inconsistent with H/W/pad/stride/dilation");
+  if (dil > 1 && d->precision == 2) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: dilated convolutions run on the precision 0 / 1 kernels");
   if ((d->x_pstride & 3) || (d->x_nstride & 3) || ((uintptr_t)d->x & 15) || ((uintptr_t)d->w & 15))
     return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: x / w must be 16-byte aligned with strides %% 4 == 0");
   if (d->N < 1 || d->Cout < 1 || (long long)d->N * d->Ho * d->Wo > 0x7fffffffLL) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: bad N/Cout");
   const bool dual = d->y2 != nullptr && d->split < d->Cout;
   p.x = d->x; p.w = d->w; p.scale = d->scale; p.bias = d->bias; p.res = d->res; p.y = d->y; p.y2 = d->y2;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
-  p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo; p.dil = dil;
   p.split = dual ? d->split : d->Cout;
   p.relu_in = d->relu_in; p.relu_out = d->relu_out;
   p.log2Cin = __builtin_ctz(d->Cin);

@@ -192,7 +192,10 @@ struct SelectArgs {
 };
 
 // ABL: ablation switch for profiling builds (0 = product, 1 = MFMA + staging only).
-template <int ABL>
+// BR: long memories (1080p, hundreds of frames): once the threshold has converged almost no score passes, so the append
+//     (address, store, fill level) is skipped by a wave-uniform branch on the compare's mask; with short memories (480p) a
+//     step nearly always has a passing lane and the branch would only add to the instruction count.
+template <int ABL, bool BR>
 __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs a) {
   __shared__ __attribute__((aligned(16))) float ktile[2][KT * KLD];
   __shared__ uint64_t cand[QT * CAP];                 // [wave][g][q][REG]
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
     auto slice_a = [&](int i) { s_pass = ((i < 4) ? p0[i & 3] : p1[i & 3]) > my_tau; };
     auto slice_b = [&](int i) {
       const unsigned long long m = __ballot(s_pass);
+      if (BR && m == 0ull) return;
       const uint32_t addr = region_lds + 8u * (uint32_t)my_cnt;
       const uint32_t idx = idx_base + (uint32_t)(16 * (i >> 2) + (i & 3));
       const uint32_t bits = __float_as_uint((i < 4) ? p0[i & 3] : p1[i & 3]);
@@ -646,14 +650,17 @@ extern "C" int mivos_memory_read_select(const float *keys, int64_t keys_ostride,
     if (!dbg_buf && hipMalloc((void **)&dbg_buf, 64) != hipSuccess) dbg_buf = nullptr;
     a.dbg = dbg_buf;
   }
+  static const int br_min = getenv("MIVOS_MEMREAD_BR_MIN") ? atoi(getenv("MIVOS_MEMREAD_BR_MIN")) : 32768;   // tuning only
   if (abl == 1)
-    hipLaunchKernelGGL(memread_select_kernel<1>, dim3(pl.n_wg), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((memread_select_kernel<1, false>), dim3(pl.n_wg), dim3(256), 0, (hipStream_t)stream, a);
+  else if (n_mem >= br_min)
+    hipLaunchKernelGGL((memread_select_kernel<0, true>), dim3(pl.n_wg), dim3(256), 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(memread_select_kernel<0>, dim3(pl.n_wg), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((memread_select_kernel<0, false>), dim3(pl.n_wg), dim3(256), 0, (hipStream_t)stream, a);
   if (dbg && dbg_buf) {
     unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    hipStreamSynchronize((hipStream_t)stream);
-    hipMemcpy(h, dbg_buf, 48, hipMemcpyDeviceToHost);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipMemcpy(h, dbg_buf, 48, hipMemcpyDeviceToHost);
     fprintf(stderr, "[memread_select] n_obj=%d n_mem=%lld n_q=%d: workgroup 0 ran %llu tiles in %llu shader-clock ticks = %.0f per tile (ideal 2048 MFMA cycles); "
             "wave 0: %llu compactions in the loop = %llu ticks, segment prologues %llu, drains + final lists %llu\n",
             n_obj, (long long)n_mem, n_q, h[1], h[0], h[1] ? (double)h[0] / (double)h[1] : 0.0, h[3], h[2], h[5], h[4]);

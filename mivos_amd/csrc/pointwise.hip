@@ -175,6 +175,67 @@ __global__ void tap_sum9_kernel(const float *__restrict__ t, const float *__rest
   }
 }
 
+// F.interpolate(mode='bilinear', align_corners=False) on an NHWC map (DeepLabV3+ head: ASPP output x4, _deeplab.py:48),
+// written into a channel slice of a wider buffer (the concatenation with the low-level features is a stride, not a copy)
+__global__ void resize_bilinear_nhwc_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t y_nstride, int64_t y_pstride, int N,
+                                            int h, int w, int H, int W, int C4) {
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const int64_t total = (int64_t)N * H * W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    int64_t t = i / C4;
+    const int ox = (int)(t % W); t /= W;
+    const int oy = (int)(t % H);
+    const int n = (int)(t / H);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilin_coord(oy, sy, h, y0, y1, ly);
+    bilin_coord(ox, sx, w, x0, x1, lx);
+    const f32x4 *u = reinterpret_cast<const f32x4 *>(x) + (int64_t)n * h * w * C4 + c;
+    const f32x4 v00 = u[((int64_t)y0 * w + x0) * C4], v01 = u[((int64_t)y0 * w + x1) * C4];
+    const f32x4 v10 = u[((int64_t)y1 * w + x0) * C4], v11 = u[((int64_t)y1 * w + x1) * C4];
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    f32x4 o;
+    o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+    o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+    o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+    o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+    *reinterpret_cast<f32x4 *>(y + (int64_t)n * y_nstride + ((int64_t)oy * W + ox) * y_pstride + 4 * c) = o;
+  }
+}
+
+// nn.AdaptiveAvgPool2d(1) on NHWC (ASPPPooling, _deeplab.py:120-131): y[n][c] = mean over the P pixels; one workgroup per
+// (image, group of 64 channels), pixels strided over the 4 waves, fixed summation order
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t P, int C) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, n = blockIdx.y;
+  float s = 0.f;
+  if (c < C)
+    for (int64_t p = wave; p < P; p += 4) s += x[((int64_t)n * P + p) * C + c];
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < C) y[(int64_t)n * C + c] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / (float)P;
+}
+
+// cv2.dilate(mask, 3x3 ones) on a binary plane (davis_processor.py:55-60): out = max over the 3x3 neighbourhood
+__global__ void dilate3x3_kernel(const float *__restrict__ x, float *__restrict__ y, int planes, int H, int W) {
+  const int64_t total = (int64_t)planes * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W);
+    int64_t r = i / W;
+    const int yy = (int)(r % H);
+    const float *pl = x + (r / H) * (int64_t)H * W;
+    float m = 0.f;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int y2 = yy + dy, x2 = xx + dx;
+        if ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W) m = fmaxf(m, pl[(int64_t)y2 * W + x2]);
+      }
+    y[i] = m;
+  }
+}
+
 __global__ void resize_bilinear_kernel(const float *__restrict__ x, float *__restrict__ y, int planes, int h, int w,
                                        int H, int W, int act) {
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
@@ -403,6 +464,26 @@ extern "C" int mivos_tap_sum9(const float *t, const float *bias, float *out, int
   if (!t || !out || N < 1 || H < 1 || W < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "tap_sum9: bad arguments");
   hipLaunchKernelGGL(tap_sum9_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 0, ST, t, bias, out, N, H, W);
   return check_launch("tap_sum9");
+}
+
+extern "C" int mivos_resize_bilinear_nhwc(const float *x, float *y, int64_t y_nstride, int64_t y_pstride, int N, int h, int w, int H, int W,
+                                          int C, void *stream) {
+  if (!x || !y || N < 1 || (C & 3) || ((y_nstride | y_pstride) & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "resize_bilinear_nhwc: bad arguments (C %% 4, 16-byte alignment)");
+  hipLaunchKernelGGL(resize_bilinear_nhwc_kernel, dim3(grid_for((int64_t)N * H * W * (C / 4))), dim3(256), 0, ST, x, y, y_nstride, y_pstride, N, h, w, H, W, C / 4);
+  return check_launch("resize_bilinear_nhwc");
+}
+
+extern "C" int mivos_global_avgpool(const float *x, float *y, int N, int64_t P, int C, void *stream) {
+  if (!x || !y || N < 1 || P < 1 || C < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "global_avgpool: bad arguments");
+  hipLaunchKernelGGL(global_avgpool_kernel, dim3(cdiv(C, 64), N), dim3(256), 0, ST, x, y, P, C);
+  return check_launch("global_avgpool");
+}
+
+extern "C" int mivos_dilate3x3(const float *x, float *y, int planes, int H, int W, void *stream) {
+  if (!x || !y || planes < 1 || H < 1 || W < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "dilate3x3: bad arguments");
+  hipLaunchKernelGGL(dilate3x3_kernel, dim3(grid_for((int64_t)planes * H * W)), dim3(256), 0, ST, x, y, planes, H, W);
+  return check_launch("dilate3x3");
 }
 
 extern "C" int mivos_area_pool16(const float *x, float *y, int planes, int H, int W, void *stream) {

@@ -19,16 +19,16 @@ from ...ops import ConvLayer
 class ConvParams(nn.Module):
     """Holds `weight` (+ `bias`) of an nn.Conv2d; no torch forward."""
 
-    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True):
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, dilation=1):
         super().__init__()
-        self.cin, self.cout, self.k, self.stride, self.padding = cin, cout, k, stride, padding
+        self.cin, self.cout, self.k, self.stride, self.padding, self.dilation = cin, cout, k, stride, padding, dilation
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
         nn.init.normal_(self.weight, 0.0, math.sqrt(2.0 / (cin * k * k)))
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
     def pack(self, bn=None, cin_pad=None):
         return ConvLayer.pack(self.weight, self.bias, None if bn is None else bn.tensors(), self.stride,
-                              self.padding, cin_pad=cin_pad, eps=1e-5 if bn is None else bn.eps)
+                              self.padding, cin_pad=cin_pad, eps=1e-5 if bn is None else bn.eps, dilation=self.dilation)
 
     def forward(self, *a, **k):
         raise RuntimeError("ConvParams is a parameter container; use the owning network's methods")
@@ -54,11 +54,11 @@ class Bottleneck(nn.Module):
     """ResNet-50 v1.5 bottleneck (mod_resnet.py:76-112; torchvision): 1x1 -> 3x3(stride) -> 1x1."""
     expansion = 4
 
-    def __init__(self, cin, width, stride, bias, downsample):
+    def __init__(self, cin, width, stride, bias, downsample, dilation=1):
         super().__init__()
         self.conv1 = ConvParams(cin, width, 1, bias=bias)
         self.bn1 = BatchNormParams(width)
-        self.conv2 = ConvParams(width, width, 3, stride=stride, padding=1, bias=bias)
+        self.conv2 = ConvParams(width, width, 3, stride=stride, padding=dilation, bias=bias, dilation=dilation)
         self.bn2 = BatchNormParams(width)
         self.conv3 = ConvParams(width, width * 4, 1, bias=bias)
         self.bn3 = BatchNormParams(width * 4)

@@ -77,13 +77,13 @@ def _nhwc_strides(t):
 
 class ConvLayer:
     """Device-resident packed convolution: OHWI weights (+ folded BN scale / bias)."""
-    __slots__ = ("w", "scale", "bias", "cin", "cout", "k", "stride", "pad", "split", "w16", "scale16", "wdma", "proj")
+    __slots__ = ("w", "scale", "bias", "cin", "cout", "k", "stride", "pad", "split", "w16", "scale16", "wdma", "proj", "dil")
 
-    def __init__(self, w_ohwi, scale, bias, stride, pad, split=None):
+    def __init__(self, w_ohwi, scale, bias, stride, pad, split=None, dil=1):
         self.w = w_ohwi.contiguous()
         self.cout, self.k, _, self.cin = w_ohwi.shape
         self.scale, self.bias = scale, bias
-        self.stride, self.pad = stride, pad
+        self.stride, self.pad, self.dil = stride, pad, dil
         self.split = self.cout if split is None else split
         self.w16 = self.scale16 = self.wdma = self.proj = None
 
@@ -139,7 +139,7 @@ class ConvLayer:
         return self.w16, self.scale16
 
     @staticmethod
-    def pack(weight, bias=None, bn=None, stride=1, pad=0, cin_pad=None, eps=1e-5):
+    def pack(weight, bias=None, bn=None, stride=1, pad=0, cin_pad=None, eps=1e-5, dilation=1):
         """weight [Cout,Cin,k,k] (+conv bias) (+ eval BatchNorm (gamma, beta, mean, var)) ->
         y = conv(x, w) * scale + bias'.   BN(conv + b) = conv*s + (b - mean)*s + beta, s = gamma/sqrt(var+eps)."""
         w = weight.detach().float()
@@ -152,8 +152,8 @@ class ConvLayer:
             gamma, beta, mean, var = (t.detach().float() for t in bn)
             s = gamma / torch.sqrt(var + eps)
             b2 = beta - mean * s if b is None else (b - mean) * s + beta
-            return ConvLayer(w, s.contiguous(), b2.contiguous(), stride, pad)
-        return ConvLayer(w, None, None if b is None else b.contiguous(), stride, pad)
+            return ConvLayer(w, s.contiguous(), b2.contiguous(), stride, pad, dil=dilation)
+        return ConvLayer(w, None, None if b is None else b.contiguous(), stride, pad, dil=dilation)
 
     @staticmethod
     def fuse_outputs(a, b):
@@ -259,6 +259,8 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
     """y = act(conv(act_in(x)) * scale + bias + res).  x: fp32 [N,H,W,Cin] view or an Act (then the LDS-DMA kernels run);
     res: fp32 view or Act; out_act=True returns an Act (only from Act inputs; `out` may be a preallocated Act, `tag` selects
     a scratch buffer).  Returns out (and out2 when the layer is split, i.e. (out, out2))."""
+    if isinstance(x, Act) and L.dil > 1:
+        x = to_f32(x)                       # atrous convolutions run on the register-staged kernels (fp32 input, bounds masks)
     from_act = isinstance(x, Act)
     if not from_act:
         _ensure_device(x)
@@ -280,8 +282,8 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
         assert out.is_contiguous() and out.numel() == n * h * w
         check(_lib.load().mivos_tap_sum9(t.data_ptr(), L.bias.data_ptr() if L.bias is not None else None, out.data_ptr(), n, h, w, _stream()))
         return out
-    ho = (h + 2 * L.pad - L.k) // L.stride + 1
-    wo = (w + 2 * L.pad - L.k) // L.stride + 1
+    ho = (h + 2 * L.pad - L.dil * (L.k - 1) - 1) // L.stride + 1
+    wo = (w + 2 * L.pad - L.dil * (L.k - 1) - 1) // L.stride + 1
     dual = L.split < L.cout
     if out is None:
         out = alloc_act(n, ho, wo, L.split, dev, tag) if out_act else torch.empty((n, ho, wo, L.split), dtype=torch.float32, device=dev)
@@ -303,7 +305,7 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
         d.x_nstride, d.x_pstride = _nhwc_strides(x)
     d.bias = L.bias.data_ptr() if L.bias is not None else None
     d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = n, h, w, cin, L.cout, L.k, L.k
-    d.stride, d.pad, d.Ho, d.Wo, d.split = L.stride, L.pad, ho, wo, L.split
+    d.stride, d.pad, d.Ho, d.Wo, d.split, d.dilation = L.stride, L.pad, ho, wo, L.split, L.dil
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)
     assert tuple(out.shape) == (n, ho, wo, L.split), (out.shape, (n, ho, wo, L.split))
     if isinstance(out, Act):
@@ -512,6 +514,38 @@ def attention_weights(mk, qk):
     w = torch.empty((b, n_mem, n_q), dtype=torch.float32, device=mk.device)
     check(_lib.load().mivos_attention_weights(mk.data_ptr(), qk.data_ptr(), qs, w.data_ptr(), b, n_mem, n_q, _stream()))
     return w
+
+
+def resize_bilinear_nhwc(x, H, W, out=None):
+    """x [N,h,w,C] fp32 dense -> [N,H,W,C] (align_corners=False); `out` may be a channel-slice view of a wider NHWC buffer."""
+    _ensure_device(x)
+    n, h, w, c = x.shape
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty((n, H, W, c), dtype=torch.float32, device=x.device)
+    assert tuple(out.shape) == (n, H, W, c) and out.stride(3) == 1 and out.stride(1) == W * out.stride(2)
+    check(_lib.load().mivos_resize_bilinear_nhwc(x.data_ptr(), out.data_ptr(), out.stride(0), out.stride(2), n, h, w, H, W, c, _stream()))
+    return out
+
+
+def global_avgpool(x):
+    """x [N,H,W,C] fp32 dense -> [N,1,1,C] (nn.AdaptiveAvgPool2d(1))."""
+    _ensure_device(x)
+    n, h, w, c = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((n, 1, 1, c), dtype=torch.float32, device=x.device)
+    check(_lib.load().mivos_global_avgpool(x.data_ptr(), y.data_ptr(), n, h * w, c, _stream()))
+    return y
+
+
+def dilate3x3(x):
+    """Binary float planes [P,H,W] -> 3x3 dilation (cv2.dilate with a 3x3 kernel of ones)."""
+    _ensure_device(x)
+    x = _f32(x).contiguous()
+    p, h, w = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().mivos_dilate3x3(x.data_ptr(), y.data_ptr(), p, h, w, _stream()))
+    return y
 
 
 def area_pool16(x):

@@ -97,6 +97,34 @@ def fuse_spec():
     _conv(s, "final_conv", 1, 32, 3, True)
     return s
 
+def s2m_spec():
+    """name -> shape for the scribble-to-mask network's state_dict (DeepLabV3+ / ResNet-50 with 6 input channels, output
+    stride 16; model/s2m/s2m_network.py:56-65, _deeplab.py:30-164, s2m_resnet.py) - 368 entries."""
+    s = OrderedDict()
+    _conv(s, "backbone.conv1", 64, 6, 7, False)
+    _bn(s, "backbone.bn1", 64)
+    cin = 64
+    for lname, width, depth in (("layer1", 64, 3), ("layer2", 128, 4), ("layer3", 256, 6), ("layer4", 512, 3)):
+        for b in range(depth):
+            p = f"backbone.{lname}.{b}."
+            _conv(s, p + "conv1", width, cin, 1, False); _bn(s, p + "bn1", width)
+            _conv(s, p + "conv2", width, width, 3, False); _bn(s, p + "bn2", width)
+            _conv(s, p + "conv3", width * 4, width, 1, False); _bn(s, p + "bn3", width * 4)
+            if b == 0:
+                _conv(s, p + "downsample.0", width * 4, cin, 1, False)
+                _bn(s, p + "downsample.1", width * 4)
+            cin = width * 4
+    _conv(s, "classifier.project.0", 48, 256, 1, False); _bn(s, "classifier.project.1", 48)
+    _conv(s, "classifier.aspp.convs.0.0", 256, 2048, 1, False); _bn(s, "classifier.aspp.convs.0.1", 256)
+    for i in (1, 2, 3):
+        _conv(s, f"classifier.aspp.convs.{i}.0", 256, 2048, 3, False); _bn(s, f"classifier.aspp.convs.{i}.1", 256)
+    _conv(s, "classifier.aspp.convs.4.1", 256, 2048, 1, False); _bn(s, "classifier.aspp.convs.4.2", 256)
+    _conv(s, "classifier.aspp.project.0", 256, 1280, 1, False); _bn(s, "classifier.aspp.project.1", 256)
+    _conv(s, "classifier.classifier.0", 256, 304, 3, False); _bn(s, "classifier.classifier.1", 256)
+    _conv(s, "classifier.classifier.3", 1, 256, 1, True)
+    return s
+
+
 # ----------------------------------------------------------------------------- values
 # Conditioning of the synthetic network (see DESIGN.md "Parity on an untrained network").  The
 # reference algorithm is discontinuous (top-k membership, argmax) and, closed-loop, feeds its own
@@ -107,6 +135,10 @@ def fuse_spec():
 MASK_CHANNEL_GAIN = 0.25   # stem weights of the mask / "others" input channels (feedback gain)
 KEY_STD = 3.0              # std of memory / query keys  => affinity std ~ 9 (sharp top-k softmax)
 LOGIT_STD = 1.5            # std of the mask logit       => confident but not saturating in fp32
+
+_S2M_HEAD_BN = {"s2m.classifier.project.1", "s2m.classifier.aspp.convs.0.1", "s2m.classifier.aspp.convs.1.1", "s2m.classifier.aspp.convs.2.1",
+                "s2m.classifier.aspp.convs.3.1", "s2m.classifier.aspp.convs.4.2", "s2m.classifier.aspp.project.1", "s2m.classifier.classifier.1"}
+
 
 def _rs(name, seed):
     return np.random.RandomState((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF)
@@ -126,7 +158,7 @@ def _draw(name, shape, seed, gain=1.0):
         v = r.standard_normal(shape) * (gain * np.sqrt(2.0 / fan_in))
         if name == "mask_rgb_encoder.conv1.weight":
             v[:, 3:] *= MASK_CHANNEL_GAIN
-    elif ".bn" in name or "downsample.1" in name:           # BN affine
+    elif ".bn" in name or "downsample.1" in name or name.rsplit(".", 1)[0] in _S2M_HEAD_BN:   # BN affine
         v = r.uniform(0.6, 1.2, shape) if leaf == "weight" else r.standard_normal(shape) * 0.1
     else:                                                   # conv bias
         v = r.standard_normal(shape) * 0.05
@@ -166,6 +198,16 @@ def make_fuse_state(seed=0, calib="golden"):
     sd = OrderedDict((k, _draw("fuse." + k, shp, seed)) for k, shp in fuse_spec().items())
     if calib == "golden":
         calib = _load_calibration("calib_fuse", seed)
+    if calib:
+        _apply_calibration(sd, calib)
+    return sd
+
+
+def make_s2m_state(seed=0, calib="golden"):
+    """Synthetic S2M state_dict; calib='golden' applies the committed BN statistics / logit gain (calib_s2m_seed{seed}.npz)."""
+    sd = OrderedDict((k, _draw("s2m." + k, shp, seed)) for k, shp in s2m_spec().items())
+    if calib == "golden":
+        calib = _load_calibration("calib_s2m", seed)
     if calib:
         _apply_calibration(sd, calib)
     return sd

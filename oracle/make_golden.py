@@ -71,9 +71,41 @@ def make_attn_golden():
     print("attn_small.npz", os.path.getsize(os.path.join(G, "attn_small.npz")) // 1024, "KiB")
 
 
+def make_s2m_golden():
+    """calib_s2m_seed0.npz, s2m_state_dict_keys.json, s2m_small.npz: the reference's scribble-to-mask network
+    (model/s2m/s2m_network.py:56-65 deeplabv3plus_resnet50) on a seeded 64x96 input."""
+    import contextlib, importlib, io
+    from oracle import s2m_oracle as SO
+    from oracle.ref_loader import load_reference
+    torch.set_grad_enabled(False)
+    load_reference()
+    calib = Wt.calibrate_s2m(0)
+    np.savez_compressed(os.path.join(G, "calib_s2m_seed0.npz"), **{k: _np(v) for k, v in calib.items()})
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = importlib.import_module("model.s2m.s2m_network").deeplabv3plus_resnet50().eval()
+    with open(os.path.join(G, "s2m_state_dict_keys.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in net.state_dict().items()}, f, indent=0)
+    sd = Wt.make_s2m_state(0)
+    net.load_state_dict(sd, strict=True)
+    # a realistic input (normalised synthetic frame, imperfect current mask, sparse positive / negative scribbles): the
+    # synthetic BN statistics are calibrated on this kind of data, white noise would give logits of +-400
+    images, gt = O.synthetic_clip(2, 64, 96, 2, seed=321)
+    g = torch.Generator().manual_seed(5)
+    cur = gt[1:2, 1] * (torch.rand(1, 1, 64, 96, generator=g) > 0.25).float()
+    pos = (torch.rand(1, 1, 64, 96, generator=g) > 0.96).float() * gt[1:2, 1]
+    neg = (torch.rand(1, 1, 64, 96, generator=g) > 0.96).float() * (1 - gt[1:2, 1])
+    x = torch.cat([images[0, 1:2], cur, pos, neg], 1)
+    out = net(x)
+    o = SO.s2m_forward(sd, x)
+    print("s2m          |oracle-ref|", float((o - out).abs().max()), "logit range", float(out.min()), float(out.max()), "std", float(out.std()))
+    np.savez_compressed(os.path.join(G, "s2m_small.npz"), s2m_in=_np(x), s2m_out=_np(out), fingerprint=np.float64(Wt.state_fingerprint(sd)))
+
+
 def main():
     if "--attn-only" in sys.argv:
         return make_attn_golden()
+    if "--s2m-only" in sys.argv:
+        return make_s2m_golden()
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
     os.makedirs(G, exist_ok=True)
@@ -198,6 +230,7 @@ def main():
     print(" ".join(trace))
     np.savez_compressed(os.path.join(G, "e2e_small.npz"), **e2e)
     make_attn_golden()
+    make_s2m_golden()
     for f in sorted(os.listdir(G)):
         print(f, os.path.getsize(os.path.join(G, f)) // 1024, "KiB")
 

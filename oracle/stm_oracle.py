@@ -35,10 +35,10 @@ def bn_calibration(store):
         _CALIB = None
 
 
-def _conv(sd, name, x, stride=1, pad=0):
+def _conv(sd, name, x, stride=1, pad=0, dilation=1):
     w = sd[name + ".weight"].to(x.dtype)
     b = sd.get(name + ".bias")
-    y = F.conv2d(x, w, None if b is None else b.to(x.dtype), stride=stride, padding=pad)
+    y = F.conv2d(x, w, None if b is None else b.to(x.dtype), stride=stride, padding=pad, dilation=dilation)
     if _CALIB is not None and name in _CALIB.get("__lsuv__", {}):
         # weight-synthesis only (oracle/weights.calibrate): rescale this conv so that its
         # output has the requested std on the calibration clip; equals scaling weight+bias.

@@ -10,7 +10,7 @@ import torch
 
 from mivos_amd.util.synthetic import *          # noqa: F401,F403
 from mivos_amd.util.synthetic import (KEY_STD, LOGIT_STD, _apply_calibration, make_fuse_state,  # noqa: F401
-                                      make_prop_state, GOLDEN_DIR, state_fingerprint, prop_spec, fuse_spec)
+                                      make_prop_state, make_s2m_state, GOLDEN_DIR, state_fingerprint, prop_spec, fuse_spec, s2m_spec)
 
 
 def calibrate(seed=0, size=(128, 160)):
@@ -57,3 +57,21 @@ def calibrate(seed=0, size=(128, 160)):
         O.fusion_net(fsd, frames[1:2], prob[0:1], gt[1, 1:2], attn, torch.tensor([[0.4, 0.6]]))
     fuse_calib = {k: v for k, v in fc.items() if k.startswith("gain:")}
     return prop_calib, fuse_calib
+
+
+def calibrate_s2m(seed=0, size=(128, 160)):
+    """BN running statistics of the synthetic S2M network (batch of 4 frames: image + current mask + positive / negative
+    scribble planes) and an LSUV gain that gives its logit the std of a trained network's (LOGIT_STD)."""
+    from . import s2m_oracle as SO
+    from . import stm_oracle as O
+    sd = make_s2m_state(seed, calib=None)
+    h, w = size
+    images, gt = O.synthetic_clip(4, h, w, 2, seed=200 + seed)
+    g = torch.Generator().manual_seed(17 + seed)
+    pos = (torch.rand(4, 1, h, w, generator=g) > 0.97).float() * gt[:, 1]
+    neg = (torch.rand(4, 1, h, w, generator=g) > 0.97).float() * (1 - gt[:, 1])
+    x = torch.cat([images[0], gt[:, 1] * (torch.rand(4, 1, h, w, generator=g) > 0.3).float(), pos, neg], 1)
+    pc = {"__lsuv__": {"classifier.classifier.3": LOGIT_STD}}
+    with O.bn_calibration(pc):
+        SO.s2m_forward(sd, x)
+    return {k: v for k, v in pc.items() if not k.startswith("__")}

@@ -26,3 +26,12 @@ def synthetic_states():
     torch.set_grad_enabled(False)
     from oracle import weights as Wt
     return Wt.make_prop_state(0), Wt.make_fuse_state(0)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _bounded_cpu_threads():
+    """The CPU oracle (oneDNN / OpenMP) scales poorly past a few dozen threads on these convolution sizes: on the 256-core
+    host of the GPU box the default (one thread per core) is several times slower than 32 threads."""
+    import torch
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    yield

@@ -350,6 +350,31 @@ def test_topk_larger_than_memory_raises_like_reference(nets):
         core.interact(gt[0], 0)
 
 
+def test_1080p_three_objects_with_fusion_vs_oracle(synthetic_states):
+    """BASELINE config 5 geometry with its object count: 1080x1920, K = 3, top_k = 50, 3 frames, interact(0) then
+    interact(2): bank depth up to T = 2, the middle frame fused (3 propagated frames; the fp64 oracle needs ~40 s per 1080p frame).  (The oracle materialises the affinity like the reference,
+    so T = 200 cannot be pinned on CPU: 160 GB; the long-bank behaviour is covered by the memory-read tests at T = 23 / 40
+    and by the size-independent checks of bench.py --config 5.)  Same gates as the 480p headline test."""
+    sd, fsd = synthetic_states
+    K = 3
+    prop, fuse = PropagationNetwork(top_k=50), FusionNet()
+    prop.load_state_dict(sd)
+    fuse.load_state_dict(fsd)
+    images, gt = O.synthetic_clip(3, 1080, 1920, K, seed=71)
+    core = InferenceCore(prop.eval(), fuse.eval(), images, K, mem_freq=1, device=DEV)
+    o32 = O.OracleCore(sd, fsd, images, K, mem_freq=1, top_k=50)
+    o64 = O.OracleCore(sd, fsd, images, K, mem_freq=1, top_k=50, dtype=torch.float64)
+    for idx in (0, 2):
+        out, r32, r64 = core.interact(gt[idx], idx), o32.interact(gt[idx], idx), o64.interact(gt[idx], idx)
+        iou = mean_iou(out, r32, K)
+        e = (core.prob.cpu().double() - o64.prob).abs().amax(dim=(0, 2, 3, 4))
+        r = (o32.prob.double() - o64.prob).abs().amax(dim=(0, 2, 3, 4))
+        print(f"1080p K=3 interact({idx}): IoU vs fp32 oracle {iou:.6f}; per-frame max|dprob| engine-fp64 {e.max():.2e} oracle32-fp64 {r.max():.2e}")
+        assert iou >= 0.999
+        assert bool((e <= 1.25 * r + 1e-4).all()), (e.tolist(), r.tolist())
+    assert core.propagated_frames == 3 and core.prob.shape == (4, 3, 1, 1088, 1920)
+
+
 def test_1080p_memory_read_and_single_step_vs_oracle(nets, synthetic_states):
     """BASELINE config 5 geometry (1080x1920 -> 1088x1920, HW = 8160), K = 1, T = 1: keys / values / logits."""
     prop, _ = nets
@@ -366,4 +391,4 @@ def test_1080p_memory_read_and_single_step_vs_oracle(nets, synthetic_states):
     got = prop.segment(k.reshape(1, -1, 128), v.reshape(1, -1, 512), q, logits=True).cpu()
     d = (got - ref).abs()
     print(f"1080p: max|dlogit| {float(d.max()):.2e}  frac(|d|>1e-3) {float((d > 1e-3).float().mean()):.2e}")
-    assert float(d.max()) < 2e-3 and float((d > LOGIT_TOL).float().mean()) < 1e-4
+    assert float(d.max()) < LOGIT_TOL

@@ -117,3 +117,21 @@ def test_attention_read_network_and_channel_aggregate(golden_dir, synthetic_stat
         lg, sm = O.aggregate_wbg_channel(g["ac_in"], keep_bg=True, hard=bool(hard))
         assert float((lg - g[f"ac_logits_{hard}"]).abs().max()) <= TOL * 1000 ** hard
         assert float((sm - g[f"ac_soft_{hard}"]).abs().max()) <= TOL
+
+
+def test_s2m_network(golden_dir):
+    """s2m_small.npz / s2m_state_dict_keys.json: the reference's deeplabv3plus_resnet50 (model/s2m) - state_dict layout of the
+    synthetic weights and the forward pass of the CPU restatement."""
+    from oracle import s2m_oracle as SO
+    keys = json.load(open(os.path.join(golden_dir, "s2m_state_dict_keys.json")))
+    assert len(keys) == 368 and {k: list(v) for k, v in Wt.s2m_spec().items()} == keys
+    with np.load(os.path.join(golden_dir, "s2m_small.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    sd = Wt.make_s2m_state(0)
+    assert Wt.state_fingerprint(sd) == pytest.approx(float(g["fingerprint"]), rel=1e-12)
+    out = SO.s2m_forward(sd, T(g["s2m_in"]))
+    assert float((out - T(g["s2m_out"])).abs().max()) <= 1e-4
+    m = torch.zeros(1, 1, 9, 9)
+    m[0, 0, 4, 4] = m[0, 0, 0, 8] = 1
+    d = SO.dilate3x3(m)
+    assert d.sum() == 9 + 4 and d[0, 0, 3:6, 3:6].min() == 1            # 3x3 max filter, zero outside the image
