@@ -6,11 +6,11 @@
 ``install()`` registers this package's modules under the import names the reference's scripts use
 (`eval_interactive_davis.py:11-15`, `interactive_gui.py:29-35`, `davis_processor.py:7-9`):
 
-    inference_core, model.propagation.prop_net, model.propagation.modules, model.fusion_net,
-    model.aggregate, model.attn_network, util.tensor_util
+    inference_core, davis_processor, model.propagation.prop_net, model.propagation.modules, model.fusion_net,
+    model.aggregate, model.attn_network, model.s2m.s2m_network, util.tensor_util
 
-Everything else of the reference (``model.s2m``, ``interact``, ``dataset``, ``davis_processor`` ...) keeps
-resolving to the reference tree, which is appended to the package search paths of ``model`` / ``util``.
+Everything else of the reference (``interact``, ``dataset``, ``model.s2s`` ...) keeps resolving to the reference
+tree, which is appended to the package search paths of ``model`` / ``util``.
 """
 import importlib
 import os
@@ -24,9 +24,12 @@ ALIASES = {
     "model.fusion_net": "mivos_amd.model.fusion_net",
     "model.aggregate": "mivos_amd.model.aggregate",
     "model.attn_network": "mivos_amd.model.attn_network",
+    "model.s2m.s2m_network": "mivos_amd.model.s2m.s2m_network",
+    "davis_processor": "mivos_amd.davis_processor",
     "util.tensor_util": "mivos_amd.util.tensor_util",
 }
-PACKAGES = {"model": "mivos_amd.model", "model.propagation": "mivos_amd.model.propagation", "util": "mivos_amd.util"}
+PACKAGES = {"model": "mivos_amd.model", "model.propagation": "mivos_amd.model.propagation", "model.s2m": "mivos_amd.model.s2m",
+            "util": "mivos_amd.util"}
 
 
 def install(reference_root=None):

@@ -12,6 +12,8 @@ def test_reference_import_lines_resolve_to_engine(tmp_path):
     fake_ref = tmp_path / "MiVOS"
     (fake_ref / "model" / "s2m").mkdir(parents=True)
     (fake_ref / "model" / "s2m" / "s2m_network.py").write_text("deeplabv3plus_resnet50 = 'reference S2M'\n")
+    (fake_ref / "model" / "s2s").mkdir(parents=True)
+    (fake_ref / "model" / "s2s" / "other.py").write_text("thing = 'reference-only module'\n")
     (fake_ref / "util").mkdir()
     (fake_ref / "util" / "palette.py").write_text("pal_color_map = 'reference palette'\n")
     script = fake_ref / "entry.py"
@@ -20,13 +22,18 @@ def test_reference_import_lines_resolve_to_engine(tmp_path):
         from model.propagation.prop_net import PropagationNetwork
         from model.fusion_net import FusionNet
         from model.s2m.s2m_network import deeplabv3plus_resnet50 as S2M
+        from model.s2s.other import thing
+        from davis_processor import DAVISProcessor
         from inference_core import InferenceCore
         from model.aggregate import aggregate_wbg, aggregate_sbg
         from util.tensor_util import pad_divide_by, unpad, unpad_3dim, compute_multi_class_iou
         from util.palette import pal_color_map
         import inspect
         assert PropagationNetwork.__module__ == 'mivos_amd.model.propagation.prop_net'
-        assert InferenceCore.__module__ == 'mivos_amd.inference_core' and S2M == 'reference S2M'
+        assert InferenceCore.__module__ == 'mivos_amd.inference_core' and thing == 'reference-only module'
+        assert S2M.__module__ == 'mivos_amd.model.s2m.s2m_network' and DAVISProcessor.__module__ == 'mivos_amd.davis_processor'
+        assert list(inspect.signature(S2M).parameters) == ['num_classes', 'output_stride', 'pretrained_backbone']
+        assert list(inspect.signature(DAVISProcessor.__init__).parameters)[1:] == ['prop_net', 'fuse_net', 's2m_net', 'images', 'num_objects', 'device']
         sig = inspect.signature(InferenceCore.__init__)
         assert list(sig.parameters)[1:] == ['prop_net', 'fuse_net', 'images', 'num_objects', 'mem_profile', 'mem_freq', 'device']
         assert sig.parameters['mem_freq'].default == 5 and sig.parameters['mem_profile'].default == 0
