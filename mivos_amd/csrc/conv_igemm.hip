@@ -207,7 +207,9 @@ using namespace mivos;
 namespace mivos {
 int conv_params_from_desc(const mivos_conv_desc *d, ConvP &p) {
   if (!d || !d->x || !d->w || !d->y) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: null pointer");
-  if (d->Cin < 4 || (d->Cin & (d->Cin - 1))) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: Cin=%d must be a power of two >= 4", d->Cin);
+  // precision 0 / 1 decode the K index with shifts (Cin a power of two); precision 2 walks 32-channel slabs (Cin % 32 == 0)
+  if (d->precision == 2 ? (d->Cin < 32 || (d->Cin & 31)) : (d->Cin < 4 || (d->Cin & (d->Cin - 1))))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: Cin=%d must be a power of two >= 4 (a multiple of 32 for precision 2)", d->Cin);
   if (d->KH != d->KW || d->KH < 1 || d->stride < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: unsupported kernel %dx%d stride %d", d->KH, d->KW, d->stride);
   const int dil = d->dilation > 1 ? d->dilation : 1;
   if (d->Ho != (d->H + 2 * d->pad - dil * (d->KH - 1) - 1) / d->stride + 1 || d->Wo != (d->W + 2 * d->pad - dil * (d->KW - 1) - 1) / d->stride + 1)
