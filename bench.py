@@ -289,6 +289,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    local = local % torch.cuda.device_count()      # (more ranks than GPUs only in the MIVOS_DIST_BACKEND=gloo plumbing test)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
 
