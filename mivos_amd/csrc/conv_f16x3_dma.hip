@@ -364,6 +364,9 @@ static int launch_pp(ConvP &p, hipStream_t st) {
 // 256 CUs), 22: 128x64 (Cout <= 64), 23: 256x256 (profiling only: equal to 20 on its best shapes).
 int select_variant_pp(int M, int Cout, int nk) {
   if (Cout <= 64) return 22;
+  // tuning only (A/B): under-filled 128x128 grids (30x54 layers: 64 row tiles) as 128x64 tiles - twice the workgroups, less split-K
+  static const int small_wgs = getenv("MIVOS_PP_SMALL_WGS") ? atoi(getenv("MIVOS_PP_SMALL_WGS")) : 0;
+  if (small_wgs && (long long)cdiv(M, 128) * cdiv(Cout, 128) <= small_wgs) return 22;
   if (Cout % 256 == 0 && nk >= 36) {      // short-K (1x1) layers are bound by loads/stores: two workgroups per CU overlap them
     const long long t = (long long)cdiv(M, 128) * (Cout / 256);
     const long long rounds = (t + 255) / 256;
