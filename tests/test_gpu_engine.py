@@ -239,21 +239,23 @@ def test_480p_single_step_logits_vs_oracle(nets, synthetic_states, K):
 
 @pytest.mark.parametrize("K", [1, 3])
 def test_480p_propagation_vs_oracle(nets, synthetic_states, K):
-    """Closed loop at 480p: 3 propagated frames, then a second interaction that fuses the frames in between.
-    Masks IoU >= 0.999.  Probabilities: both fp32 implementations drift from an fp64 run of the same
-    algorithm by up to ~1e-3 after a few fed-back frames (measured: scripts/debug_e2e.py), so
-    the closed-loop probability tolerance is 2.5e-3; the single-step test above holds the 1e-3 logit bar."""
+    """Closed loop at 480p, top_k = 20 (config 2's setting): 3 propagated frames, then a second interaction that fuses the
+    frames in between.  Masks IoU >= 0.999; probabilities gated like the headline test below: per frame the engine may be at
+    most twice as far from an fp64 run of the oracle as the fp32 oracle itself, plus the 1e-3-logit equivalent."""
     prop, fuse = nets
     sd, fsd = synthetic_states
     images, gt = O.synthetic_clip(4, 480, 854, K, seed=20 + K)
     core = InferenceCore(prop, fuse, images, K, mem_freq=2, device=DEV)
     ocore = O.OracleCore(sd, fsd, images, K, mem_freq=2, top_k=20)
+    o64 = O.OracleCore(sd, fsd, images, K, mem_freq=2, top_k=20, dtype=torch.float64)
     for idx in (0, 3):                                               # second one fuses frames 1, 2
-        out, ref = core.interact(gt[idx], idx), ocore.interact(gt[idx], idx)
-        iou, dp = mean_iou(out, ref, K), float((core.prob.cpu() - ocore.prob).abs().max())
-        print(f"K={K} interact({idx}): IoU {iou:.6f} max|dprob| {dp:.2e}")
+        out, ref, _ = core.interact(gt[idx], idx), ocore.interact(gt[idx], idx), o64.interact(gt[idx], idx)
+        iou = mean_iou(out, ref, K)
+        e = (core.prob.cpu().double() - o64.prob).abs().amax(dim=(0, 2, 3, 4))
+        r = (ocore.prob.double() - o64.prob).abs().amax(dim=(0, 2, 3, 4))
+        print(f"K={K} interact({idx}): IoU {iou:.6f} per-frame max|dprob| engine-fp64 {e.max():.2e} oracle32-fp64 {r.max():.2e}")
         assert iou >= 0.999
-        assert dp < 2.5e-3
+        assert bool((e <= 2.0 * r + 2.5e-4).all()), (e.tolist(), r.tolist())
 
 
 @pytest.mark.parametrize("K,top_k,frames", [(5, 50, 8), (2, 50, 5)])

@@ -233,3 +233,15 @@ def test_memory_read_work_partition(n_obj, n_mem, n_q, top_k):
         w_first, w_last = (s * tps) // per_wg, ((s + 1) * tps - 1) // per_wg
         assert used[s] == set(range(w_last - w_first + 1))
     assert lib.mivos_memory_read_workspace_bytes(n_obj, n_mem, n_q, top_k) == streams * slots * 64 * L * 8
+
+
+def test_activation_batches_are_capped_by_bytes():
+    """the LDS-DMA kernels address one SH32 tensor with 32-bit offsets (< 2 GB); object / query batches are chunked
+    by ops.max_act_batch (the largest bordered activation of the trunks / decoder is 256 channels at 1/4 resolution)."""
+    from mivos_amd import ops
+    per_image = lambda h, w: (h // 4 + 2) * (w // 4 + 2) * 256 * 4
+    for h, w in [(480, 864), (1088, 1920), (2160, 3840)]:
+        cap = ops.max_act_batch(h // 4, w // 4, 256)
+        assert cap >= 1 and cap * per_image(h, w) <= ops.ACT_BYTES_LIMIT < (cap + 1) * per_image(h, w)
+    assert ops.max_act_batch(120, 216, 256) == 78 and ops.max_act_batch(272, 480, 256) == 15 and ops.max_act_batch(540, 960, 256) == 4
+    assert ops.max_act_batch(100000, 100000, 256) == 1            # never zero: a single image is attempted (and refused by the library)
