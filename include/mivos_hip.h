@@ -291,8 +291,9 @@ int mivos_ingest_u8(const uint8_t *frames, float *out, int T, int H, int W, int6
 /* F.interpolate(mode='bicubic', align_corners=False) (yv_test_dataset.py:107): planes [P][h][w] -> [P][H][W]. */
 int mivos_resize_bicubic(const float *x, float *out, int planes, int h, int w, int H, int W, int64_t out_pstride,
                          int64_t out_rstride, int pad_top, int pad_left, void *stream);
-/* Palette-index label map [h][w] uint8 -> one-hot float planes for labels[0..n_labels) (device pointer), resized with the
- * 'nearest' rule of yv_test_dataset.py:108 (src = floor(dst * in / out)); dataset/onehot_util semantics. */
+/* Palette-index label map [h][w] uint8 -> n_labels + 1 one-hot float planes (plane 0 = background = none of the labels,
+ * plane 1 + k = labels[k]; labels is a device pointer), resized with the 'nearest' rule of yv_test_dataset.py:108
+ * (src = floor(dst * in / out)): the `mask` argument of InferenceCore.interact (inference_core.py:219). */
 int mivos_onehot_nearest(const uint8_t *label_map, const uint8_t *labels, int n_labels, float *out, int h, int w, int H,
                          int W, int64_t out_pstride, int64_t out_rstride, int pad_top, int pad_left, void *stream);
 

@@ -72,8 +72,7 @@ def onehot_mask(label_map_u8, labels, device="cuda:0", resize_to=None):
         lv = torch.as_tensor(np.asarray(labels, dtype=np.uint8)).to(dev)
         k = lv.numel()
         out = torch.empty((k + 1, 1, oh, ow), dtype=torch.float32, device=dev)
-        check(_lib.load().mivos_onehot_nearest(lab.data_ptr(), lv.data_ptr(), k, out[1:].data_ptr(), H, W, oh, ow, oh * ow, ow, 0, 0, ops._stream()))
-        out[0] = 1.0 - out[1:].sum(0).clamp(max=1.0)
+        check(_lib.load().mivos_onehot_nearest(lab.data_ptr(), lv.data_ptr(), k, out.data_ptr(), H, W, oh, ow, oh * ow, ow, 0, 0, ops._stream()))
     return out
 
 

@@ -76,8 +76,9 @@ __global__ void resize_bicubic_kernel(const float *__restrict__ x, float *__rest
   }
 }
 
-// label map [h][w] uint8 (palette indices) -> one-hot float planes for `n_labels` labels, resized with torch's 'nearest'
-// rule (src = floor(dst * in / out)), at out + k*out_pstride + (Y + pad_top)*out_rstride + X + pad_left
+// label map [h][w] uint8 (palette indices) -> one-hot float planes: plane 0 = background (none of the labels), plane 1 + k =
+// labels[k], resized with torch's 'nearest' rule (src = floor(dst * in / out)), at out + plane*out_pstride +
+// (Y + pad_top)*out_rstride + X + pad_left
 __global__ void onehot_nearest_kernel(const uint8_t *__restrict__ lab, const uint8_t *__restrict__ labels, int n_labels,
                                       float *__restrict__ out, int h, int w, int H, int W, int64_t out_pstride,
                                       int64_t out_rstride, int pad_top, int pad_left) {
@@ -90,7 +91,13 @@ __global__ void onehot_nearest_kernel(const uint8_t *__restrict__ lab, const uin
     xx = xx > w - 1 ? w - 1 : xx;
     const uint8_t v = lab[(int64_t)yy * w + xx];
     float *o = out + (int64_t)(Y + pad_top) * out_rstride + X + pad_left;
-    for (int k = 0; k < n_labels; ++k) o[(int64_t)k * out_pstride] = v == labels[k] ? 1.f : 0.f;
+    bool any = false;
+    for (int k = 0; k < n_labels; ++k) {
+      const bool hit = v == labels[k];
+      any |= hit;
+      o[(int64_t)(k + 1) * out_pstride] = hit ? 1.f : 0.f;
+    }
+    o[0] = any ? 0.f : 1.f;
   }
 }
 

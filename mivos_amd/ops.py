@@ -215,7 +215,11 @@ def act_path():
 
 def alloc_act(n, h, w, c, device, tag=None):
     """Zero-bordered SH32 buffer.  tag=None: fresh storage (for tensors the caller keeps); otherwise a scratch buffer
-    cached per (tag, shape) whose interior the next producer overwrites completely (the border is zeroed once)."""
+    cached per (tag, shape, device, stream) whose interior the next producer overwrites completely (the border is zeroed once).
+    Sharing scratch between call sites - and between several InferenceCores - is safe because every use is stream ordered: a
+    scratch tensor is written by one launch and read by launches enqueued right after it on the SAME stream, so a later
+    producer (of whichever core) is ordered behind the last reader.  Nothing that outlives the enclosing network call may live in
+    scratch: cached query features, bank slots and public results use tag=None / their own tensors."""
     if c % 32:
         raise MivosHipError(f"SH32 activations need a multiple of 32 channels, got {c}")
     if tag is None:
