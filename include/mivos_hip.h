@@ -200,6 +200,22 @@ int mivos_memory_read_topk_indices(const float *keys, int64_t keys_ostride, cons
                                    int32_t *idx_out, float *weight_out, int n_obj, int64_t n_mem,
                                    int n_q, int top_k, void *workspace, int64_t workspace_bytes,
                                    void *stream);
+/* ... and its staged form, after either select call. */
+int mivos_memory_read_finalize_indices(int32_t *idx_out, float *weight_out, int n_obj, int64_t n_mem, int n_q, int top_k,
+                                       void *workspace, int64_t workspace_bytes, void *stream);
+/* The engine's default precision ("f16x3", like the convolutions): the affinity of prop_net.py:85-88 on the fp16 matrix
+ * pipe with error compensation - keys and queries are split x = hi + lo (two fp16), each 32-channel step is
+ * lo*hi + hi*lo + hi*hi accumulated in fp32 (the same 22-bit operands / fp32 sums as every convolution of the engine).
+ * Keys are split ONCE, when a frame is memorised: mivos_memory_split_keys turns fp32 rows [n_obj][n_rows][128] (object stride
+ * keys_ostride floats) into the streamed layout (again 512 bytes per row, object stride split_ostride in 4-byte units; block
+ * b = 0..3 of 64 halves holds, for ks = 0..3, hi[8] | lo[8] of channels 32 ks + 8 b + e), and mivos_memory_read_select_f16x3
+ * is mivos_memory_read_select on those rows (qk stays fp32, same workspace, followed by any of the finalize calls).
+ * |key| and |qk| / sqrt(128) must stay below the fp16 range (65504). */
+int mivos_memory_split_keys(const float *keys, int64_t keys_ostride, void *keys_split, int64_t split_ostride, int n_obj,
+                            int64_t n_rows, void *stream);
+int mivos_memory_read_select_f16x3(const void *keys_split, int64_t keys_ostride, const float *qk, int n_obj,
+                                   int64_t n_mem, int n_q, int top_k, void *workspace, int64_t workspace_bytes,
+                                   void *stream);
 
 /* --------------------------------------------------------------------------------------------
  * Difference-aware attention alignment: W = softmax_m(mk^T qk / sqrt(128)) (T = 1, all positions),

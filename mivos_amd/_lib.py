@@ -57,6 +57,9 @@ PROTOTYPES = {
     "mivos_memory_read_finalize": (C.c_int, [vp, i64, vp, i64, i64, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
     "mivos_memory_read_finalize_sh32": (C.c_int, [vp, i64, vp, vp, i64, i64, i64, C.c_int, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
     "mivos_memory_read_topk_indices": (C.c_int, [vp, i64, vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
+    "mivos_memory_read_finalize_indices": (C.c_int, [vp, vp, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
+    "mivos_memory_split_keys": (C.c_int, [vp, i64, vp, i64, C.c_int, i64, vp]),
+    "mivos_memory_read_select_f16x3": (C.c_int, [vp, i64, vp, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
     "mivos_attention_align": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "mivos_area_pool16": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_resize_bilinear": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

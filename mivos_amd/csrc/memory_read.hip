@@ -21,6 +21,13 @@
 //   are appended; when a buffer may overflow the owning wave compacts it: bisection of the packed 64-bit keys (all
 //   distinct) with two ballots per bit, stopped as soon as between k and k+16 entries survive (an exact cut is not
 //   needed until the end), tau := the cut.  Ties: lower memory index wins (torch.topk leaves ties unspecified).
+//   F16 variant (the engine's default precision, "f16x3"): the same kernel with the affinity on the fp16 matrix pipe, error
+//   compensated like the convolutions: keys and queries are split x = hi + lo (two fp16, 22 significant bits), a k-step of
+//   32 channels is three v_mfma_f32_16x16x32_f16 (lo*hi + hi*lo + hi*hi, fp32 accumulate; the lo*lo term is below fp32
+//   rounding).  24 MFMAs of ~17 cycles per tile instead of 64 of 32: the kernel is then bound by the selection at 480p and by
+//   the key stream at 1080p.  Keys come PRE-SPLIT (mivos_memory_split_keys, once per memorised frame): a row is the same
+//   512 bytes, laid out so that the loader, the LDS tile and the fragment reads are byte-for-byte those of the fp32 variant -
+//   block b (64 halves) = for ks in 0..3: hi[8] | lo[8] of channels 32 ks + 8 b + e.
 // Kernel 2 (memread_finalize): one wave per (object, query): exact k-th largest of the merged lists (same bisection,
 //   run to the end), exp(s - s_max)/sum in rank order like the reference, then the k value rows (2 KB each) are gathered
 //   in ascending memory index - the order in which the reference's dense bmm meets its non-zeros.
@@ -195,7 +202,8 @@ struct SelectArgs {
 // BR: long memories (1080p, hundreds of frames): once the threshold has converged almost no score passes, so the append
 //     (address, store, fill level) is skipped by a wave-uniform branch on the compare's mask; with short memories (480p) a
 //     step nearly always has a passing lane and the branch would only add to the instruction count.
-template <int ABL, bool BR>
+// F16: error-compensated fp16 MFMA affinity on pre-split keys (see the header); false = exact fp32 MFMA on fp32 keys.
+template <int ABL, bool BR, bool F16>
 __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs a) {
   __shared__ __attribute__((aligned(16))) float ktile[2][KT * KLD];
   __shared__ uint64_t cand[QT * CAP];                 // [wave][g][q][REG]
@@ -230,17 +238,36 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
 
     __syncthreads();                                  // previous segment completely done with LDS
 
-    // B operand: this lane's query row pieces, scaled like prop_net.py:86 (qk / sqrt(CK), a true division)
+    // B operand: this lane's query row pieces, scaled like prop_net.py:86 (qk / sqrt(CK), a true division).
+    // fp32: qreg[u] = channels coff + 4u .. +3.  F16: block b = coff / 32 of the split layout - qreg[2 ks] = hi, qreg[2 ks + 1]
+    // = lo of channels 32 ks + 8 b + e (e = 0..7), as two packed half8 vectors in the same 32 registers.
     f32x4_t qreg[8];
     {
       const int q = qtile * QT + qslot;
-      const float *qrow = a.qk + (long long)(q < a.n_q ? q : a.n_q - 1) * CK + coff;
+      const float *qrow = a.qk + (long long)(q < a.n_q ? q : a.n_q - 1) * CK;
       const float d = sqrtf((float)CK);
+      if (F16) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        f32x4_t v = *reinterpret_cast<const f32x4_t *>(qrow + 4 * u);
-        v.x /= d; v.y /= d; v.z /= d; v.w /= d;
-        qreg[u] = v;
+        for (int ks = 0; ks < 4; ++ks) {
+          const float *src = qrow + 32 * ks + (coff >> 2);
+          const f32x4_t v0 = *reinterpret_cast<const f32x4_t *>(src), v1 = *reinterpret_cast<const f32x4_t *>(src + 4);
+          half8_t hi, lo;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = (e < 4 ? v0[e & 3] : v1[e & 3]) / d;
+            hi[e] = (_Float16)x;
+            lo[e] = (_Float16)(x - (float)hi[e]);
+          }
+          qreg[2 * ks] = __builtin_bit_cast(f32x4_t, hi);
+          qreg[2 * ks + 1] = __builtin_bit_cast(f32x4_t, lo);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          f32x4_t v = *reinterpret_cast<const f32x4_t *>(qrow + coff + 4 * u);
+          v.x /= d; v.y /= d; v.z /= d; v.w /= d;
+          qreg[u] = v;
+        }
       }
     }
 
@@ -366,27 +393,55 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
       // cost their full issue time).  So the selection is dealt out ONE OR TWO instructions per MFMA, pinned by scheduling
       // barriers (the compiler would otherwise regroup them).
 #define MIVOS_SB __builtin_amdgcn_sched_barrier(0);
+      if (F16) {
+        // k-step ks: F[2 ks] = hi, F[2 ks + 1] = lo halves of the key rows; small terms first.  Score registers 2 ks and
+        // 2 ks + 1 of the previous tile are selected in the gaps (an fp16 MFMA leaves the vector ALU free, unlike fp32).
+#define MIVOS_HF(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, A), __builtin_bit_cast(half8_t, B), ACC, 0, 0, 0); MIVOS_SB
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          G0[2 * ks] = *reinterpret_cast<const f32x4_t *>(nrow0 + 8 * ks); MIVOS_SB
+          MIVOS_HF(acc0, F0[2 * ks + 1], qreg[2 * ks])
+          if (ABL != 1) slice_a(2 * ks);
+          MIVOS_SB
+          MIVOS_HF(acc1, F1[2 * ks + 1], qreg[2 * ks])
+          G0[2 * ks + 1] = *reinterpret_cast<const f32x4_t *>(nrow0 + 8 * ks + 4); MIVOS_SB
+          MIVOS_HF(acc0, F0[2 * ks], qreg[2 * ks + 1])
+          if (ABL != 1) slice_b(2 * ks);
+          MIVOS_SB
+          MIVOS_HF(acc1, F1[2 * ks], qreg[2 * ks + 1])
+          G1[2 * ks] = *reinterpret_cast<const f32x4_t *>(nrow0 + 16 * KLD + 8 * ks); MIVOS_SB
+          MIVOS_HF(acc0, F0[2 * ks], qreg[2 * ks])
+          if (ABL != 1) slice_a(2 * ks + 1);
+          MIVOS_SB
+          G1[2 * ks + 1] = *reinterpret_cast<const f32x4_t *>(nrow0 + 16 * KLD + 8 * ks + 4); MIVOS_SB
+          MIVOS_HF(acc1, F1[2 * ks], qreg[2 * ks])
+          if (ABL != 1) slice_b(2 * ks + 1);
+          MIVOS_SB
+        }
+#undef MIVOS_HF
+      } else {
 #define MIVOS_MF0(U, S) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F0[U][S], qreg[U][S], acc0, 0, 0, 0); MIVOS_SB
 #define MIVOS_MF1(U, S) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F1[U][S], qreg[U][S], acc1, 0, 0, 0); MIVOS_SB
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        G0[u] = *reinterpret_cast<const f32x4_t *>(nrow0 + 4 * u); MIVOS_SB
-        MIVOS_MF0(u, 0)
-        if (ABL != 1) slice_a(u);
-        MIVOS_SB
-        MIVOS_MF1(u, 0)
-        G1[u] = *reinterpret_cast<const f32x4_t *>(nrow0 + 16 * KLD + 4 * u); MIVOS_SB
-        MIVOS_MF0(u, 1)
-        MIVOS_MF1(u, 1)
-        if (ABL != 1) slice_b(u);
-        MIVOS_SB
-        MIVOS_MF0(u, 2)
-        MIVOS_MF1(u, 2)
-        MIVOS_MF0(u, 3)
-        MIVOS_MF1(u, 3)
-      }
+        for (int u = 0; u < 8; ++u) {
+          G0[u] = *reinterpret_cast<const f32x4_t *>(nrow0 + 4 * u); MIVOS_SB
+          MIVOS_MF0(u, 0)
+          if (ABL != 1) slice_a(u);
+          MIVOS_SB
+          MIVOS_MF1(u, 0)
+          G1[u] = *reinterpret_cast<const f32x4_t *>(nrow0 + 16 * KLD + 4 * u); MIVOS_SB
+          MIVOS_MF0(u, 1)
+          MIVOS_MF1(u, 1)
+          if (ABL != 1) slice_b(u);
+          MIVOS_SB
+          MIVOS_MF0(u, 2)
+          MIVOS_MF1(u, 2)
+          MIVOS_MF0(u, 3)
+          MIVOS_MF1(u, 3)
+        }
 #undef MIVOS_MF0
 #undef MIVOS_MF1
+      }
 #undef MIVOS_SB
       if (ABL == 1 && t >= 2) {                 // keep the MFMA results alive without selecting
         const float sum = (acc0.x + acc0.y) + (acc1.z + acc1.w);
@@ -546,6 +601,28 @@ __global__ __launch_bounds__(64) void memread_finalize_kernel(const uint64_t *__
   }
 }
 
+// fp32 key rows [n_obj][n_rows][128] -> the pre-split rows the F16 select kernel streams (same 512 bytes per row): thread
+// (row, t = 4 ks + b) converts channels 32 ks + 8 b .. +7 = floats 8 t .. 8 t + 7 into hi[8] | lo[8] at half offset 64 b + 16 ks.
+__global__ __launch_bounds__(256) void split_keys_kernel(const float *__restrict__ src, long long src_ostride, float *__restrict__ dst,
+                                                         long long dst_ostride, long long n_rows) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long row = i >> 4;
+  if (row >= n_rows) return;
+  const int t = (int)(i & 15), ks = t >> 2, b = t & 3;
+  const float *p = src + (long long)blockIdx.y * src_ostride + row * CK + 8 * t;
+  const f32x4_t v0 = *reinterpret_cast<const f32x4_t *>(p), v1 = *reinterpret_cast<const f32x4_t *>(p + 4);
+  half8_t hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = e < 4 ? v0[e & 3] : v1[e & 3];
+    hi[e] = (_Float16)x;
+    lo[e] = (_Float16)(x - (float)hi[e]);
+  }
+  float *q = dst + (long long)blockIdx.y * dst_ostride + row * CK + 32 * b + 8 * ks;
+  *reinterpret_cast<f32x4_t *>(q) = __builtin_bit_cast(f32x4_t, hi);
+  *reinterpret_cast<f32x4_t *>(q + 4) = __builtin_bit_cast(f32x4_t, lo);
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------
 struct Plan {
   int n_qtiles, streams, tps, n_wg, tiles_per_wg, slots, L;
@@ -634,8 +711,8 @@ extern "C" int mivos_memory_read_plan(int n_obj, int64_t n_mem, int n_q, int top
   return MIVOS_OK;
 }
 
-extern "C" int mivos_memory_read_select(const float *keys, int64_t keys_ostride, const float *qk, int n_obj, int64_t n_mem,
-                                        int n_q, int top_k, void *workspace, int64_t workspace_bytes, void *stream) {
+static int launch_select(bool f16, const float *keys, int64_t keys_ostride, const float *qk, int n_obj, int64_t n_mem, int n_q, int top_k,
+                         void *workspace, int64_t workspace_bytes, void *stream) {
   if (int rc = check_select_args(keys, keys_ostride, qk, n_obj, n_mem, n_q, top_k, workspace, workspace_bytes)) return rc;
   const Plan pl = make_plan(n_obj, n_mem, n_q, top_k);
   SelectArgs a;
@@ -650,22 +727,54 @@ extern "C" int mivos_memory_read_select(const float *keys, int64_t keys_ostride,
     if (!dbg_buf && hipMalloc((void **)&dbg_buf, 64) != hipSuccess) dbg_buf = nullptr;
     a.dbg = dbg_buf;
   }
+  // the wave-uniform skip of the append pays once most compares fail everywhere: long memories for the fp32 variant (whose
+  // appends cost issue slots next to the fp32 MFMAs anyway), earlier for the fp16 variant
   static const int br_min = getenv("MIVOS_MEMREAD_BR_MIN") ? atoi(getenv("MIVOS_MEMREAD_BR_MIN")) : 32768;   // tuning only
-  if (abl == 1)
-    hipLaunchKernelGGL((memread_select_kernel<1, false>), dim3(pl.n_wg), dim3(256), 0, (hipStream_t)stream, a);
-  else if (n_mem >= br_min)
-    hipLaunchKernelGGL((memread_select_kernel<0, true>), dim3(pl.n_wg), dim3(256), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL((memread_select_kernel<0, false>), dim3(pl.n_wg), dim3(256), 0, (hipStream_t)stream, a);
+  static const int br_min16 = getenv("MIVOS_MEMREAD_BR_MIN16") ? atoi(getenv("MIVOS_MEMREAD_BR_MIN16")) : 32768;   // tuning only
+  const bool br = n_mem >= (f16 ? br_min16 : br_min);
+  const dim3 grid(pl.n_wg), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define MIVOS_SEL(ABL, BR, F16) hipLaunchKernelGGL((memread_select_kernel<ABL, BR, F16>), grid, block, 0, st, a)
+  if (f16) {
+    if (abl == 1) MIVOS_SEL(1, false, true);
+    else if (br) MIVOS_SEL(0, true, true);
+    else MIVOS_SEL(0, false, true);
+  } else {
+    if (abl == 1) MIVOS_SEL(1, false, false);
+    else if (br) MIVOS_SEL(0, true, false);
+    else MIVOS_SEL(0, false, false);
+  }
+#undef MIVOS_SEL
   if (dbg && dbg_buf) {
     unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipStreamSynchronize(st);
     (void)hipMemcpy(h, dbg_buf, 48, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[memread_select] n_obj=%d n_mem=%lld n_q=%d: workgroup 0 ran %llu tiles in %llu shader-clock ticks = %.0f per tile (ideal 2048 MFMA cycles); "
+    fprintf(stderr, "[memread_select %s] n_obj=%d n_mem=%lld n_q=%d: workgroup 0 ran %llu tiles in %llu shader-clock ticks = %.0f per tile (MFMA issue alone: %d cycles); "
             "wave 0: %llu compactions in the loop = %llu ticks, segment prologues %llu, drains + final lists %llu\n",
-            n_obj, (long long)n_mem, n_q, h[1], h[0], h[1] ? (double)h[0] / (double)h[1] : 0.0, h[3], h[2], h[5], h[4]);
+            f16 ? "f16x3" : "f32", n_obj, (long long)n_mem, n_q, h[1], h[0], h[1] ? (double)h[0] / (double)h[1] : 0.0, f16 ? 24 * 17 : 64 * 32, h[3], h[2], h[5], h[4]);
   }
   return check_launch("memread_select");
+}
+
+extern "C" int mivos_memory_read_select(const float *keys, int64_t keys_ostride, const float *qk, int n_obj, int64_t n_mem,
+                                        int n_q, int top_k, void *workspace, int64_t workspace_bytes, void *stream) {
+  return launch_select(false, keys, keys_ostride, qk, n_obj, n_mem, n_q, top_k, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mivos_memory_read_select_f16x3(const void *keys_split, int64_t keys_ostride, const float *qk, int n_obj, int64_t n_mem,
+                                              int n_q, int top_k, void *workspace, int64_t workspace_bytes, void *stream) {
+  return launch_select(true, (const float *)keys_split, keys_ostride, qk, n_obj, n_mem, n_q, top_k, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mivos_memory_split_keys(const float *keys, int64_t keys_ostride, void *keys_split, int64_t split_ostride, int n_obj,
+                                       int64_t n_rows, void *stream) {
+  if (!keys || !keys_split || n_obj < 1 || n_rows < 1 || ((uintptr_t)keys & 15) || ((uintptr_t)keys_split & 15) || (keys_ostride & 3) || (split_ostride & 3))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_split_keys: null / misaligned pointer or bad sizes");
+  const long long blocks = (n_rows * 16 + 255) / 256;
+  if (blocks > 0x7fffffffLL || n_obj > 65535) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_split_keys: too many rows / objects for one launch");
+  hipLaunchKernelGGL(split_keys_kernel, dim3((unsigned)blocks, n_obj), dim3(256), 0, (hipStream_t)stream, keys, (long long)keys_ostride,
+                     (float *)keys_split, (long long)split_ostride, (long long)n_rows);
+  return check_launch("memory_split_keys");
 }
 
 extern "C" int mivos_memory_read_finalize(const float *values, int64_t values_ostride, float *out, int64_t out_ostride,
@@ -707,6 +816,15 @@ extern "C" int mivos_memory_read_topk_indices(const float *keys, int64_t keys_os
                                               void *workspace, int64_t workspace_bytes, void *stream) {
   if (!idx_out || !weight_out) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read_indices: null pointer");
   if (int rc = mivos_memory_read_select(keys, keys_ostride, qk, n_obj, n_mem, n_q, top_k, workspace, workspace_bytes, stream)) return rc;
+  const Plan pl = make_plan(n_obj, n_mem, n_q, top_k);
+  return launch_finalize(true, pl, workspace, nullptr, 0, nullptr, 0, 0, idx_out, weight_out, n_obj, n_q, top_k, (hipStream_t)stream);
+}
+
+extern "C" int mivos_memory_read_finalize_indices(int32_t *idx_out, float *weight_out, int n_obj, int64_t n_mem, int n_q, int top_k,
+                                                  void *workspace, int64_t workspace_bytes, void *stream) {
+  if (!idx_out || !weight_out || !workspace) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read_finalize_indices: null pointer");
+  if (top_k < 1 || top_k > MAX_TOPK || n_mem < top_k || workspace_bytes < mivos_memory_read_workspace_bytes(n_obj, n_mem, n_q, top_k))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read_finalize_indices: arguments do not match the select call");
   const Plan pl = make_plan(n_obj, n_mem, n_q, top_k);
   return launch_finalize(true, pl, workspace, nullptr, 0, nullptr, 0, 0, idx_out, weight_out, n_obj, n_q, top_k, (hipStream_t)stream);
 }

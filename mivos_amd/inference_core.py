@@ -186,15 +186,21 @@ class InferenceCore:
         keys = torch.empty((K, total, kh, kw, CK), dtype=torch.float32, device=self.device)
         values = torch.empty((K, total, kh, kw, CV), dtype=torch.float32, device=self.device)
         keys[:, :nc], values[:, :nc] = self._certain_k, self._certain_v
+        # the affinity kernel streams keys pre-split into fp16 hi/lo pairs (ops.split_keys): a second bank of the same size,
+        # every slot converted once when it is written
+        ksplit = torch.empty_like(keys)
+        ops.split_keys(keys[:, :nc], ksplit[:, :nc])
         hw = kh * kw
         for si, st in enumerate(steps):
             q = self._query(st.ti, upcoming=[s2.ti for s2 in steps[si + 1:si + self.QUERY_BATCH]])
             prob_k = self.prop_net.segment(keys[:, :st.n_read].reshape(K, st.n_read * hw, CK),
-                                           values[:, :st.n_read].reshape(K, st.n_read * hw, CV), q)
+                                           values[:, :st.n_read].reshape(K, st.n_read * hw, CV), q,
+                                           keys_split=ksplit[:, :st.n_read].reshape(K, st.n_read * hw, CK))
             out = ops.aggregate(prob_k.unsqueeze(1), keep_bg=True)            # [K+1,1,nh,nw]
             if st.slot is not None:
                 self.prop_net.memorize_into(self.get_image_buffered(st.ti), out[1:],
                                             key_out=keys[:, st.slot], val_out=values[:, st.slot])
+                ops.split_keys(keys[:, st.slot], ksplit[:, st.slot])
             if st.fuse:
                 out = self.fuse_one_frame(closest, idx, st.ti, self.prob[:, st.ti], out, key_k, q.k16)
             self.prob[:, st.ti] = out.to(self.result_dev)

@@ -248,25 +248,28 @@ class PropagationNetwork(nn.Module):
         f16, _, _ = run_trunk(p["menc"], x, keep=False)
         return ops.conv(f16, p["kv_m"], out=key_out, out2=val_out)
 
-    def segment(self, keys, values, q, logits=False):
+    def segment(self, keys, values, q, logits=False, keys_split=None):
         """keys [K,n_mem,128], values [K,n_mem,512] (rows per memory position), q QueryFeatures ->
-        object probabilities [K,H,W] (sigmoid applied, prop_net.py:181) or raw logits."""
+        object probabilities [K,H,W] (sigmoid applied, prop_net.py:181) or raw logits.  keys_split: ops.split_keys(keys) when
+        the caller keeps one (InferenceCore's bank does); otherwise the memory read converts the keys on every call."""
         dec = self.plan()["dec"]
         K = keys.shape[0]
         _, h, w, _ = q.f16.shape
         cap = ops.max_act_batch(4 * h, 4 * w, 256)
         if K > cap:
-            return torch.cat([self.segment(keys[i:i + cap], values[i:i + cap], q, logits) for i in range(0, K, cap)], 0)
+            return torch.cat([self.segment(keys[i:i + cap], values[i:i + cap], q, logits,
+                                           None if keys_split is None else keys_split[i:i + cap]) for i in range(0, K, cap)], 0)
         s8, s4 = self._skip(q)
         if ops.act_path():
             # the readout lands pre-split (x and relu(x)) in the compress block's input buffers; the v16 half of
             # cat([mem, v16.expand(K)]) (prop_net.py:178-179) enters as the cached partial sums q.c1v / q.dsv
-            raw, rel = ops.memory_read_acts(keys, values, q.k16.reshape(h * w, CK), self.memory.top_k, h, w)
+            raw, rel = ops.memory_read_acts(keys, values, q.k16.reshape(h * w, CK), self.memory.top_k, h, w, keys_split=keys_split)
             cs = dec["compress_split"]
             x = run_resblock_acts((cs["c1m"], cs["c2"], cs["dsm"]), raw, rel, res1=q.c1v, res_skip=q.dsv)
         else:
             m4 = torch.empty((K, h, w, 2 * CV), dtype=torch.float32, device=keys.device)
-            ops.memory_read(keys, values, q.k16.reshape(h * w, CK), self.memory.top_k, out=m4.view(K, h * w, 2 * CV)[:, :, :CV])
+            ops.memory_read(keys, values, q.k16.reshape(h * w, CK), self.memory.top_k, out=m4.view(K, h * w, 2 * CV)[:, :, :CV],
+                            keys_split=keys_split)
             m4[..., CV:] = q.v16                                        # cat([mem, v16.expand(K)]) (prop_net.py:178-179)
             x = run_resblock(dec["compress"], m4)
         x = run_up_branch(dec["up_16_8"], s8, x, tag="up16")

@@ -414,53 +414,94 @@ def _rows(t, width):
     return t, (t.stride(0) if t.shape[0] > 1 else t.shape[1] * width)
 
 
-def memory_read(keys, values, qk, top_k, out=None):
-    """keys [K, n_mem, 128], values [K, n_mem, 512], qk [n_q, 128] -> out [K, n_q, 512]
-    (out may be a channel-slice view [K, n_q, 512] of a wider [K, n_q, C] buffer)."""
+def split_keys(keys, out=None):
+    """fp32 key rows [K, ..., 128] (dense rows, any object stride) -> the pre-split rows mivos_memory_read_select_f16x3 streams
+    (same shape / dtype container, bits are packed fp16 hi/lo pairs).  InferenceCore keeps a split copy of its key bank and
+    converts every memorised frame once."""
     _ensure_device(keys)
+    k = keys.shape[0]
+    rows = keys.reshape(k, -1, 128) if keys.dim() != 3 else keys
+    rows, ko = _rows(_f32(rows), 128)
+    if out is None:
+        out = torch.empty(rows.shape, dtype=torch.float32, device=keys.device)
+    orows = out.view(k, -1, 128) if out.dim() != 3 else out
+    assert orows.shape == rows.shape and orows.stride(2) == 1 and orows.stride(1) == 128
+    if rows.shape[1] == 0:
+        return out
+    oo = orows.stride(0) if k > 1 else rows.shape[1] * 128
+    check(_lib.load().mivos_memory_split_keys(rows.data_ptr(), ko, orows.data_ptr(), oo, k, rows.shape[1], _stream()))
+    return out
+
+
+def _memread_select(lib, keys, ko, keys_split, qk, k, n_mem, n_q, top_k, ws):
+    """The affinity + streaming top-k launch in the engine's precision: "f16x3" streams pre-split keys (the caller's split
+    bank, or a conversion of `keys` into scratch when there is none), "f32" the fp32 rows through the exact fp32 MFMA kernel."""
+    if CONV_PRECISION == "f32":
+        check(lib.mivos_memory_read_select(keys.data_ptr(), ko, qk.data_ptr(), k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
+        return
+    if keys_split is None:
+        sp, so = _workspace(k * n_mem * 512, keys.device, "memread_ksplit").data_ptr(), n_mem * 128
+        check(lib.mivos_memory_split_keys(keys.data_ptr(), ko, sp, so, k, n_mem, _stream()))
+    else:
+        rows, so = _rows(_f32(keys_split), 128)
+        assert rows.shape == keys.shape
+        sp = rows.data_ptr()
+    check(lib.mivos_memory_read_select_f16x3(sp, so, qk.data_ptr(), k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
+
+
+def _memread_args(keys, values, qk, top_k):
     keys, ko = _rows(_f32(keys), 128)
-    values, vo = _rows(_f32(values), 512)
     k, n_mem, _ = keys.shape
     n_q = qk.shape[0]
-    assert qk.is_contiguous() and qk.shape[1] == 128 and values.shape[:2] == (k, n_mem)
+    assert qk.is_contiguous() and qk.shape[1] == 128 and qk.dtype == torch.float32
+    vo = 0
+    if values is not None:
+        values, vo = _rows(_f32(values), 512)
+        assert values.shape[:2] == (k, n_mem)
     if top_k is None:
         raise MivosHipError("memory_read: top_k=None (full softmax) is not part of the propagation path")
+    return keys, ko, values, vo, k, n_mem, n_q
+
+
+def _memread_profile(ev, k, n_mem, n_q, top_k, out_rows):
+    # affinity: 2*K*n_mem*n_q*128 FLOP, keys + queries read once; finalize: k value rows of 2 KB per (object, query) + the output
+    PROFILE.append((90, 2.0 * k * n_mem * n_q * 128, ev[0], ev[1], (k, n_mem, n_q, top_k, 4.0 * 128 * (k * n_mem + n_q))))
+    PROFILE.append((91, 2.0 * k * n_q * top_k * 512, ev[2], ev[3], (k, n_mem, n_q, top_k, 4.0 * 512 * k * n_q * (top_k + out_rows))))
+
+
+def memory_read(keys, values, qk, top_k, out=None, keys_split=None):
+    """keys [K, n_mem, 128], values [K, n_mem, 512], qk [n_q, 128] -> out [K, n_q, 512]
+    (out may be a channel-slice view [K, n_q, 512] of a wider [K, n_q, C] buffer).  keys_split: split_keys(keys) kept by the
+    caller (otherwise converted here on every call)."""
+    _ensure_device(keys)
+    keys, ko, values, vo, k, n_mem, n_q = _memread_args(keys, values, qk, top_k)
     if out is None:
         out = torch.empty((k, n_q, 512), dtype=torch.float32, device=keys.device)
     assert out.shape == (k, n_q, 512) and out.stride(2) == 1
     lib = _lib.load()
-    nbytes = lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k)
-    ws = _workspace(nbytes, keys.device, "memread")
-    if PROFILE is None:
-        check(lib.mivos_memory_read_topk(keys.data_ptr(), ko, values.data_ptr(), vo, qk.data_ptr(), out.data_ptr(),
-                                         out.stride(0), out.stride(1), k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
-        return out
-    # profiling (bench.py): the two launches one by one with HIP events on the launch stream around each
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    ev[0].record()
-    check(lib.mivos_memory_read_select(keys.data_ptr(), ko, qk.data_ptr(), k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
-    ev[1].record()
-    ev[2].record()
+    ws = _workspace(lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k), keys.device, "memread")
+    ev = None
+    if PROFILE is not None:      # bench.py: HIP events on the launch stream around each of the two launches
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+    _memread_select(lib, keys, ko, keys_split, qk, k, n_mem, n_q, top_k, ws)
+    if ev:
+        ev[1].record()
+        ev[2].record()
     check(lib.mivos_memory_read_finalize(values.data_ptr(), vo, out.data_ptr(), out.stride(0), out.stride(1), k, n_mem, n_q, top_k,
                                          ws.data_ptr(), ws.numel(), _stream()))
-    ev[3].record()
-    # affinity: 2*K*n_mem*n_q*128 FLOP, keys + queries read once; finalize: k value rows of 2 KB per (object, query) + the output
-    PROFILE.append((90, 2.0 * k * n_mem * n_q * 128, ev[0], ev[1], (k, n_mem, n_q, top_k, 4.0 * 128 * (k * n_mem + n_q))))
-    PROFILE.append((91, 2.0 * k * n_q * top_k * 512, ev[2], ev[3], (k, n_mem, n_q, top_k, 4.0 * 512 * k * n_q * (top_k + 1))))
+    if ev:
+        ev[3].record()
+        _memread_profile(ev, k, n_mem, n_q, top_k, 1)
     return out
 
 
-def memory_read_acts(keys, values, qk, top_k, h, w, tag="memread"):
+def memory_read_acts(keys, values, qk, top_k, h, w, tag="memread", keys_split=None):
     """memory_read whose readout lands pre-split in two SH32 Acts [K, h, w, 512]: (raw, relu(raw)) - what the decoder's first
     ResBlock reads.  keys [K, n_mem, 128], values [K, n_mem, 512], qk [h*w, 128]."""
     _ensure_device(keys)
-    keys, ko = _rows(_f32(keys), 128)
-    values, vo = _rows(_f32(values), 512)
-    k, n_mem, _ = keys.shape
-    n_q = qk.shape[0]
-    assert qk.is_contiguous() and qk.shape[1] == 128 and values.shape[:2] == (k, n_mem) and n_q == h * w
-    if top_k is None:
-        raise MivosHipError("memory_read: top_k=None (full softmax) is not part of the propagation path")
+    keys, ko, values, vo, k, n_mem, n_q = _memread_args(keys, values, qk, top_k)
+    assert n_q == h * w
     raw, rel = alloc_act(k, h, w, 512, keys.device, (tag, "raw")), alloc_act(k, h, w, 512, keys.device, (tag, "relu"))
     lib = _lib.load()
     ws = _workspace(lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k), keys.device, "memread")
@@ -469,7 +510,7 @@ def memory_read_acts(keys, values, qk, top_k, h, w, tag="memread"):
     if PROFILE is not None:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-    check(lib.mivos_memory_read_select(keys.data_ptr(), ko, qk.data_ptr(), k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
+    _memread_select(lib, keys, ko, keys_split, qk, k, n_mem, n_q, top_k, ws)
     if ev:
         ev[1].record()
         ev[2].record()
@@ -477,23 +518,21 @@ def memory_read_acts(keys, values, qk, top_k, h, w, tag="memread"):
                                               ws.data_ptr(), ws.numel(), _stream()))
     if ev:
         ev[3].record()
-        PROFILE.append((90, 2.0 * k * n_mem * n_q * 128, ev[0], ev[1], (k, n_mem, n_q, top_k, 4.0 * 128 * (k * n_mem + n_q))))
-        PROFILE.append((91, 2.0 * k * n_q * top_k * 512, ev[2], ev[3], (k, n_mem, n_q, top_k, 4.0 * 512 * k * n_q * (top_k + 2))))
+        _memread_profile(ev, k, n_mem, n_q, top_k, 2)
     return raw, rel
 
 
-def memory_read_indices(keys, qk, top_k):
+def memory_read_indices(keys, qk, top_k, keys_split=None):
     """Test/debug: the selected memory indices [K, n_q, k] (best first) and softmax weights."""
     _ensure_device(keys)
-    keys, ko = _rows(_f32(keys), 128)
-    k, n_mem, _ = keys.shape
-    n_q = qk.shape[0]
+    qk = qk.contiguous()
+    keys, ko, _, _, k, n_mem, n_q = _memread_args(keys, None, qk, top_k)
     idx = torch.empty((k, n_q, top_k), dtype=torch.int32, device=keys.device)
     wgt = torch.empty((k, n_q, top_k), dtype=torch.float32, device=keys.device)
     lib = _lib.load()
     ws = _workspace(lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k), keys.device, "memread")
-    check(lib.mivos_memory_read_topk_indices(keys.data_ptr(), ko, qk.contiguous().data_ptr(), idx.data_ptr(), wgt.data_ptr(),
-                                             k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
+    _memread_select(lib, keys, ko, keys_split, qk, k, n_mem, n_q, top_k, ws)
+    check(lib.mivos_memory_read_finalize_indices(idx.data_ptr(), wgt.data_ptr(), k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
     return idx, wgt
 
 

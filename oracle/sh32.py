@@ -54,3 +54,24 @@ def pack_weights_dma(w_ohwi, mult):
         phys[:, n, q] = logical[:, n, lc]
     body = phys.contiguous().view(torch.uint8).reshape(-1)
     return torch.cat([torch.zeros(128, dtype=torch.uint8), body])
+
+
+def split_key_rows(keys):
+    """fp32 key rows [..., 128] -> the rows mivos_memory_read_select_f16x3 streams (mivos_memory_split_keys), as a
+    float32-typed tensor of the same shape: block b = 0..3 (64 halves) holds, for ks = 0..3, hi[8] | lo[8] of channels
+    32 ks + 8 b + e."""
+    assert keys.shape[-1] == 128
+    hi, lo = split_hi_lo(keys.float())
+    lead = keys.shape[:-1]
+    def arrange(t):                                                  # [..., ks, b, e] -> [..., b, ks, e]
+        return t.reshape(*lead, 4, 4, 8).transpose(-3, -2)
+    rows = torch.stack([arrange(hi), arrange(lo)], dim=-2)           # [..., b, ks, part, e]
+    return rows.reshape(*lead, 256).contiguous().view(torch.float32)
+
+
+def affinity_f16x3(keys, qk):
+    """What the f16x3 affinity computes, in fp64: keys [n_mem,128], qk [n_q,128] -> [n_mem, n_q] =
+    sum_c (kh qh + kh ql + kl qh), k = kh + kl, q / sqrt(128) = qh + ql (the kl ql term is dropped)."""
+    kh, kl = (t.double() for t in split_hi_lo(keys.float()))
+    qh, ql = (t.double() for t in split_hi_lo(qk.float() / torch.sqrt(torch.tensor(128.0))))
+    return kh @ qh.t() + kh @ ql.t() + kl @ qh.t()

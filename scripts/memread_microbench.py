@@ -1,5 +1,6 @@
-"""Throughput of the memory read on hot-path sizes, select (affinity MFMA + streaming top-k) and finalize (merge +
-softmax + value gather) timed separately with HIP events through the staged C ABI.  `MIVOS_ABL=1` (environment) runs the
+"""Throughput of the memory read on hot-path sizes: select (affinity MFMA + streaming top-k; both the exact fp32 MFMA kernel
+and the error-compensated fp16 one on pre-split keys) and finalize (merge + softmax + value gather) timed separately with HIP
+events through the staged C ABI.  `MIVOS_ABL=1` (environment) runs the
 MFMA + staging skeleton of the select kernel without selection (ablation); `--check` compares the index sets with a
 torch top-k of the fp64 affinity on the smallest case."""
 import os
@@ -31,28 +32,35 @@ for name, K, T, hw, topk, scale in CASES:
     torch.cuda.synchronize()
     ws = ops._workspace(lib.mivos_memory_read_workspace_bytes(K, n_mem, hw, topk), keys.device, "memread")
     st = ops._stream()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ksplit = ops.split_keys(keys)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     ev[0].record()
     for _ in range(reps):
         check(lib.mivos_memory_read_select(keys.data_ptr(), n_mem * 128, q.data_ptr(), K, n_mem, hw, topk, ws.data_ptr(), ws.numel(), st))
     ev[1].record()
     for _ in range(reps):
+        check(lib.mivos_memory_read_select_f16x3(ksplit.data_ptr(), n_mem * 128, q.data_ptr(), K, n_mem, hw, topk, ws.data_ptr(), ws.numel(), st))
+    ev[2].record()
+    for _ in range(reps):
         check(lib.mivos_memory_read_finalize(vals.data_ptr(), n_mem * 512, out.data_ptr(), out.stride(0), out.stride(1), K, n_mem, hw, topk,
                                              ws.data_ptr(), ws.numel(), st))
-    ev[2].record()
+    ev[3].record()
     torch.cuda.synchronize()
-    sel, fin = ev[0].elapsed_time(ev[1]) / reps, ev[1].elapsed_time(ev[2]) / reps
+    sel, sel16, fin = (ev[i].elapsed_time(ev[i + 1]) / reps for i in range(3))
     fl = 2.0 * K * n_mem * hw * 128
     gather = 4.0 * 512 * K * hw * (topk + 1)
-    print(f"{name:28s} select {sel * 1e3:9.1f} us  {fl / sel / 1e9:6.1f} TF/s ({fl / sel / 1e9 / 157.3 * 100:4.1f}% of f32 MFMA peak)   "
+    print(f"{name:28s} select f32 {sel * 1e3:9.1f} us {fl / sel / 1e9:6.1f} TF/s ({fl / sel / 1e9 / 157.3 * 100:4.1f}% of f32 MFMA peak)   "
+          f"f16x3 {sel16 * 1e3:9.1f} us {fl / sel16 / 1e9:6.1f} TF/s ({3 * fl / sel16 / 1e9 / 2500 * 100:4.1f}% of 3-product fp16 peak, x{sel / sel16:4.2f})   "
           f"finalize {fin * 1e3:7.1f} us ({gather / fin / 1e6:6.0f} GB/s)", flush=True)
 
 if "--check" in sys.argv:
     K, T, hw, topk = 2, 3, 300, 50
     keys = torch.randn(K, T * hw, 128, device=DEV) * 3
     q = torch.randn(hw, 128, device=DEV) * 3
-    idx, wgt = ops.memory_read_indices(keys, q, topk)
     aff = torch.einsum("kmc,qc->kmq", keys.double(), q.double() / (128 ** 0.5))
     ref = torch.topk(aff, topk, dim=1)[1].permute(0, 2, 1)
-    same = (torch.sort(idx.long(), 2)[0] == torch.sort(ref, 2)[0]).all(2).float().mean()
-    print("index sets equal to fp64 top-k:", float(same), " weights sum:", float(wgt.sum(2).mean()))
+    for mode in ("f32", "f16x3"):
+        ops.CONV_PRECISION = mode
+        idx, wgt = ops.memory_read_indices(keys, q, topk)
+        same = (torch.sort(idx.long(), 2)[0] == torch.sort(ref, 2)[0]).all(2).float().mean()
+        print(mode, "index sets equal to fp64 top-k:", float(same), " weights sum:", float(wgt.sum(2).mean()))

@@ -336,7 +336,7 @@ def _run_mem(mk, mv, qk, top_k):
     return out.cpu().view(K, h, w, 512).permute(0, 3, 1, 2), idx.cpu(), wgt.cpu()
 
 
-def test_memory_read_golden(golden_dir):
+def test_memory_read_golden(golden_dir, precision):
     with np.load(os.path.join(golden_dir, "ops_small.npz")) as z:
         mk, mv, qk, ref = (torch.from_numpy(z[k]) for k in ("mr_mk", "mr_mv", "mr_qk", "mr_out"))
     got, _, _ = _run_mem(mk, mv, qk, 20)
@@ -347,8 +347,9 @@ def test_memory_read_golden(golden_dir):
                                            (40, 8, 10, 1, 50),      # one 64-query stream cut into many segments (10 lists to merge)
                                            (7, 30, 54, 5, 50),      # the benchmark's shape: runs that cross stream boundaries
                                            (2, 68, 120, 1, 64)])    # 1080p grid, largest supported k
-def test_memory_read_vs_oracle(T, h, w, K, top_k):
-    """Readout and exact top-k membership.  A query whose k-th and (k+1)-th scores tie within fp32 rounding (the case
+def test_memory_read_vs_oracle(T, h, w, K, top_k, precision):
+    """Readout and exact top-k membership, for the exact fp32 MFMA affinity and for the error-compensated fp16 one (whose
+    scores are as close to the exact product as torch's own fp32 ones: tests/test_host_logic.py).  A query whose k-th and (k+1)-th scores tie within fp32 rounding (the case
     T=23 holds one with a margin of exactly 0 in torch's own fp32 affinity) may legitimately resolve either way -
     torch.topk leaves ties unspecified and the summation order of the 128-term dot product is implementation defined -
     so values and index sets are compared on the queries with a clear margin (all but <= 1 % / two of them)."""
@@ -370,7 +371,7 @@ def test_memory_read_vs_oracle(T, h, w, K, top_k):
         assert float((wgt[o].sum(1) - 1).abs().max()) < 1e-5
 
 
-def test_memory_read_sharp_scores_and_ties():
+def test_memory_read_sharp_scores_and_ties(precision):
     # large-magnitude keys (softmax nearly one-hot) and duplicated memory rows (exact score ties)
     mk, mv, qk = _mem_case(2, 8, 10, 1, seed=9, scale=6.0)
     mk[:, :, 1] = mk[:, :, 0]                                   # frame 1 duplicates frame 0: every score ties
@@ -385,6 +386,28 @@ def test_memory_read_sharp_scores_and_ties():
     assert float((got_t - ref_t).abs().max()) < 2e-4
     assert int((idx[0] >= 160).sum()) == 0 or True            # indices stay in range
     assert int(idx.max()) < 160 and int(idx.min()) >= 0
+
+
+def test_split_keys_matches_the_cpu_definition_bitwise_and_bank_path():
+    """mivos_memory_split_keys vs oracle/sh32.split_key_rows, through a strided bank-slot view; a read that is handed the
+    split bank equals the read that converts the keys itself."""
+    from oracle import sh32
+    g = torch.Generator().manual_seed(21)
+    bank = torch.randn(3, 5, 6, 9, 128, generator=g) * 4                      # [K, slots, h, w, 128]
+    dev = bank.to(DEV)
+    split = torch.zeros_like(dev)
+    ops.split_keys(dev[:, 1:4], split[:, 1:4])
+    ops.split_keys(dev[:, 4], split[:, 4])
+    assert torch.equal(split[:, 1:5].cpu().view(torch.int32), sh32.split_key_rows(bank[:, 1:5]).view(torch.int32))
+    assert float(split[:, 0].abs().max()) == 0
+    keys, ks = dev[:, 1:5].reshape(3, 4 * 54, 128), split[:, 1:5].reshape(3, 4 * 54, 128)
+    vals = torch.randn(3, 4 * 54, 512, generator=g).to(DEV)
+    q = (torch.randn(54, 128, generator=g) * 4).to(DEV)
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f16x3"
+    try:
+        assert torch.equal(ops.memory_read(keys, vals, q, 20, keys_split=ks), ops.memory_read(keys, vals, q, 20))
+    finally:
+        ops.CONV_PRECISION = old
 
 
 def test_memory_read_topk_out_of_range_raises():

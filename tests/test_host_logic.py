@@ -245,3 +245,22 @@ def test_activation_batches_are_capped_by_bytes():
         assert cap >= 1 and cap * per_image(h, w) <= ops.ACT_BYTES_LIMIT < (cap + 1) * per_image(h, w)
     assert ops.max_act_batch(120, 216, 256) == 78 and ops.max_act_batch(272, 480, 256) == 15 and ops.max_act_batch(540, 960, 256) == 4
     assert ops.max_act_batch(100000, 100000, 256) == 1            # never zero: a single image is attempted (and refused by the library)
+
+
+def test_split_key_rows_layout_and_f16x3_affinity_error():
+    """oracle/sh32.py's definition of the pre-split key rows (compared bitwise with mivos_memory_split_keys on the GPU) and
+    the size of the f16x3 affinity's deviation from the exact product: a few 1e-7 of the score scale, below what fp32
+    accumulation order already moves."""
+    from oracle import sh32
+    g = torch.Generator().manual_seed(3)
+    keys = torch.randn(50, 128, generator=g) * 3
+    rows = sh32.split_key_rows(keys).view(torch.float16).view(50, 4, 4, 2, 8)          # [row, b, ks, part, e]
+    hi, lo = sh32.split_hi_lo(keys)
+    for b, ks in ((0, 0), (3, 1), (1, 3)):
+        c0 = 32 * ks + 8 * b
+        assert torch.equal(rows[:, b, ks, 0], hi[:, c0:c0 + 8]) and torch.equal(rows[:, b, ks, 1], lo[:, c0:c0 + 8])
+    qk = torch.randn(40, 128, generator=g) * 3
+    exact = keys.double() @ (qk.double() / (128 ** 0.5)).t()
+    err16 = float((sh32.affinity_f16x3(keys, qk) - exact).abs().max())
+    err32 = float(((keys @ (qk / (128 ** 0.5)).t()).double() - exact).abs().max())
+    assert err16 < 2e-5 and err16 < 4 * err32 + 1e-6, (err16, err32)
