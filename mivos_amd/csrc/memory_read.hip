@@ -33,6 +33,8 @@
 //   in ascending memory index - the order in which the reference's dense bmm meets its non-zeros.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace mivos {
@@ -195,8 +197,19 @@ struct SelectArgs {
   int tps;                // tiles per stream
   long long total_tiles;
   int tiles_per_wg, slots, L;
+  int *header;               // first 64 bytes of the workspace: the plan this launch used, for the finalize kernel
+  int qt;                    // queries per workgroup (QT, or QT2 for the 32-queries-per-wave kernel)
   unsigned long long *dbg;   // profiling builds: {shader cycles, tiles} of workgroup 0 / wave 0 (NULL otherwise)
 };
+
+// The finalize kernel takes the work partition from the workspace header the select launch left there (the two select
+// kernels cut the work differently; a finalize call only repeats the sizes).
+constexpr int HEADER_BYTES = 64;
+__device__ __forceinline__ void write_plan_header(const SelectArgs &a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.header[0] = a.qt; a.header[1] = a.n_qtiles; a.header[2] = a.tps; a.header[3] = a.tiles_per_wg; a.header[4] = a.slots; a.header[5] = a.L;
+  }
+}
 
 // ABL: ablation switch for profiling builds (0 = product, 1 = MFMA + staging only).
 // BR: long memories (1080p, hundreds of frames): once the threshold has converged almost no score passes, so the append
@@ -222,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
   const bool prof = a.dbg && blockIdx.x == 0;       // profiling builds only (MIVOS_MEMREAD_DBG)
   const unsigned long long clk0 = prof ? __builtin_readcyclecounter() : 0ull;
   unsigned long long clk_room = 0ull, clk_final = 0ull, clk_pro = 0ull, n_compact = 0ull;
+  write_plan_header(a);
 
   while (t_begin < t_end) {
     const int stream = (int)(t_begin / a.tps);
@@ -487,6 +501,281 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
   }
 }
 
+// ---- the 32-queries-per-wave variant of the fp16 kernel ------------------------------------------------------------
+// Same work partition, staging, candidate handling and lists as memread_select_kernel<.., F16 = true>, but a workgroup
+// covers QT2 = 128 queries: each wave holds 32 queries (64 VGPRs of hi/lo fp16 B fragments) and runs
+// v_mfma_f32_32x32x16_f16 on the 32-key tile, so a key fragment read from LDS serves twice as many queries - the fp16
+// kernel above is bound by the LDS traffic of the key tile (80 KB moved per 32 keys x 64 queries), not by its 24 MFMAs.
+//   Per tile and wave: 8 k-steps of 16 channels x 3 products = 24 MFMAs (32 cycles each), 16 ds_read_b128.
+//   Lane (j, h) = (lane & 31, lane >> 5) owns the 16 scores of query j against keys 8 (r >> 2) + 4 h + (r & 3), r = 0..15,
+//   one threshold and ONE candidate region of REG2 entries; a query's two regions (h = 0, 1) are compacted together.
+//   The pre-split key rows are the same bytes: chunk (ks, h) of the fp16 k-step is at float offset 16 ks + 8 h (hi; lo at
+//   + 4) of the row and holds channels 64 (ks & 1) + 32 h + 8 (ks >> 1) + e.
+constexpr int QW2 = 32;                       // queries per wave
+constexpr int QT2 = 128;                      // queries per workgroup
+constexpr int REG2 = 61;                      // entries per region (odd: 16 consecutive lanes' regions walk all bank pairs)
+constexpr int REG2_TRIGGER = REG2 - 1 - 8;    // room is made before each group of 8 appends per lane (twice per tile)
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__device__ __forceinline__ int compact_query2(uint64_t *buf, int n0, int n1, int k, int lane, float &new_tau) {
+  constexpr int GS = QW2 * REG2;                       // region h of this query starts at buf + h * GS
+  wave_lds_handoff();
+  uint64_t raw[2], e[2];
+  raw[0] = lane < n0 ? buf[lane] : 0ull;
+  raw[1] = lane < n1 ? buf[GS + lane] : 0ull;
+  e[0] = lane < n0 ? raw_to_key(raw[0]) : 0ull;
+  e[1] = lane < n1 ? raw_to_key(raw[1]) : 0ull;
+  int c = n0 + n1;
+  uint64_t p = 1ull;                                   // one region nearly full, few entries overall: only rebalance
+  if (c > k + SLACK) p = bisect_kth<2>(e, k, SLACK, c);
+  int base = 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const bool keep = e[t] >= p;
+    const unsigned long long m = __ballot(keep);
+    const int r = base + __popcll(m & below);         // rank among the survivors -> region r & 1, slot r >> 1
+    if (keep) buf[(r & 1) * GS + (r >> 1)] = raw[t];
+    base += __popcll(m);
+  }
+  wave_lds_handoff();
+  if (p != 1ull) new_tau = ord2f((uint32_t)(p >> 32));
+  return c;
+}
+
+template <int ABL, bool BR>
+__global__ __launch_bounds__(256, 1) void memread_select32_kernel(const SelectArgs a) {
+  __shared__ __attribute__((aligned(16))) float ktile[2][KT * KLD];
+  __shared__ uint64_t cand[QT2 * 2 * REG2];           // [wave][h][j][REG2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int qslot = wave * QW2 + j;
+  const int lrow = tid >> 3, lc = tid & 7;           // key-tile loader: row tid>>3, float4 columns lc + 8 jj
+
+  long long t_begin = (long long)blockIdx.x * a.tiles_per_wg;
+  const long long t_end = (t_begin + a.tiles_per_wg < a.total_tiles) ? t_begin + a.tiles_per_wg : a.total_tiles;
+  const bool prof = a.dbg && blockIdx.x == 0;       // profiling builds only (MIVOS_MEMREAD_DBG)
+  const unsigned long long clk0 = prof ? __builtin_readcyclecounter() : 0ull;
+  unsigned long long clk_room = 0ull, clk_final = 0ull, clk_pro = 0ull, n_compact = 0ull;
+  write_plan_header(a);
+
+  while (t_begin < t_end) {
+    const int stream = (int)(t_begin / a.tps);
+    const int seg_lo = (int)(t_begin - (long long)stream * a.tps);
+    int seg_hi = seg_lo + (int)(t_end - t_begin);
+    if (seg_hi > a.tps) seg_hi = a.tps;
+    const int nt = seg_hi - seg_lo;
+    const int obj = stream / a.n_qtiles, qtile = stream - obj * a.n_qtiles;
+    const int slot = (int)blockIdx.x - (int)(((long long)stream * a.tps) / a.tiles_per_wg);
+    const int r0 = seg_lo * KT;
+    const int r1 = ((long long)seg_hi * KT < a.n_mem) ? seg_hi * KT : (int)a.n_mem;
+    const float *kbase = a.keys + (long long)obj * a.keys_ostride;
+
+    __syncthreads();                                  // previous segment completely done with LDS
+
+    // B operand: query j, scaled like prop_net.py:86, split hi/lo; qf[2 ks] = hi, qf[2 ks + 1] = lo of chunk (ks, h)
+    f32x4_t qf[16];
+    {
+      const int q = qtile * QT2 + qslot;
+      const float *qrow = a.qk + (long long)(q < a.n_q ? q : a.n_q - 1) * CK + 32 * h;
+      const float d = sqrtf((float)CK);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const float *src = qrow + 64 * (ks & 1) + 8 * (ks >> 1);
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t *>(src), v1 = *reinterpret_cast<const f32x4_t *>(src + 4);
+        half8_t hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = (e < 4 ? v0[e & 3] : v1[e & 3]) / d;
+          hi[e] = (_Float16)x;
+          lo[e] = (_Float16)(x - (float)hi[e]);
+        }
+        qf[2 * ks] = __builtin_bit_cast(f32x4_t, hi);
+        qf[2 * ks + 1] = __builtin_bit_cast(f32x4_t, lo);
+      }
+    }
+
+    f32x4_t krA[4], krB[4];
+    auto gload = [&](f32x4_t (&kr)[4], int kb) {
+      const int m = kb + lrow;                        // rows past the segment's end: its first row instead (never selected)
+      const f32x4_t *src = reinterpret_cast<const f32x4_t *>(kbase + (long long)(m < r1 ? m : r0) * CK) + lc;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) kr[jj] = src[8 * jj];
+    };
+    auto lds_store = [&](f32x4_t (&kr)[4], int buf) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4_t *>(&ktile[buf][lrow * KLD + 4 * (lc + 8 * jj)]) = kr[jj];
+    };
+
+    float my_tau = -INFINITY;
+    uint64_t *const my_region = cand + ((wave * 2 + h) * QW2 + j) * REG2;
+    const uint32_t region_lds = (uint32_t)(size_t)my_region;
+    int my_cnt = 0;
+    // Append path of one score (see memread_select_kernel): compare, index, LDS address, a store executed by the passing
+    // lanes only, fill level.  `sc` is read straight from the PREVIOUS tile's accumulators while the matrix pipe works on the
+    // current tile (two accumulator sets, even / odd tiles): no latch phase between tiles, and the previous tile's last MFMA
+    // retired a whole tile ago.
+    bool s_pass;
+    float sc;
+    uint32_t idx_base = 0u;                           // previous tile's base row + 4h: index of score r = idx_base + 8 (r >> 2) + (r & 3)
+    auto slice_a = [&](const f32x16_t (&pv)[2], int r) { sc = pv[0][r] + pv[1][r]; s_pass = sc > my_tau; };
+    auto slice_b = [&](int r) {
+      const unsigned long long m = __ballot(s_pass);
+      if (BR && m == 0ull) return;
+      const uint32_t addr = region_lds + 8u * (uint32_t)my_cnt;
+      const uint32_t idx = idx_base + (uint32_t)(8 * (r >> 2) + (r & 3));
+      const uint32_t bits = __float_as_uint(sc);
+      unsigned long long saved;
+      asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write2_b32 %2, %3, %4 offset1:1\n\ts_mov_b64 exec, %0"
+                   : "=&s"(saved) : "s"(m), "v"(addr), "v"(idx), "v"(bits) : "memory");
+      my_cnt += s_pass ? 1 : 0;
+    };
+    auto compact_one = [&](int ql, bool force) {
+      const int n0 = __builtin_amdgcn_readlane(my_cnt, ql), n1 = __builtin_amdgcn_readlane(my_cnt, ql + 32);
+      if (force && n0 + n1 <= a.top_k + SLACK) return;
+      float nt_tau = my_tau;
+      const int c = compact_query2(cand + (wave * 2 * QW2 + ql) * REG2, n0, n1, a.top_k, lane, nt_tau);
+      if (j == ql) { my_cnt = (c - h + 1) >> 1; my_tau = nt_tau; }
+    };
+    auto make_room = [&]() {
+      const unsigned long long full = __ballot(my_cnt > REG2_TRIGGER);
+      unsigned need = (unsigned)(full | (full >> 32));
+      if (need) {
+        const unsigned long long c0 = prof ? __builtin_readcyclecounter() : 0ull;
+        while (need) {
+          const int ql = __builtin_ctz(need);
+          need &= need - 1;
+          compact_one(ql, false);
+          n_compact += prof ? 1 : 0;
+        }
+        if (prof) clk_room += __builtin_readcyclecounter() - c0;
+      }
+    };
+
+    const unsigned long long cpro = prof ? __builtin_readcyclecounter() : 0ull;
+    f32x4_t fa[16], fb[16];
+    gload(krA, r0);
+    if (nt > 1) gload(krB, r0 + KT);
+    lds_store(krA, 0);
+    if (nt > 1) lds_store(krB, 1);
+    if (nt > 2) gload(krA, r0 + 2 * KT);
+    if (nt > 3) gload(krB, r0 + 3 * KT);
+    __syncthreads();
+    {
+      const float *arow = &ktile[0][j * KLD + 8 * h];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        fa[2 * ks] = *reinterpret_cast<const f32x4_t *>(arow + 16 * ks);
+        fa[2 * ks + 1] = *reinterpret_cast<const f32x4_t *>(arow + 16 * ks + 4);
+      }
+    }
+    __syncthreads();                                  // every wave holds tile 0 in registers: its LDS copy is dead
+    if (prof) clk_pro += __builtin_readcyclecounter() - cpro;
+
+    // One tile: MFMAs on fragment set F (tile t) into accumulator set `cur` while G receives tile t+1's fragments, tile
+    // t+2 goes from its staging registers to LDS (over tile t's dead copy), tile t+4 is requested, and tile t-1's scores
+    // (accumulator set `pv`) are selected.  Everything is dealt out between the MFMAs, pinned by scheduling barriers.
+    f32x16_t accA[2], accB[2];
+    auto tile_iter = [&](int t, f32x4_t (&F)[16], f32x4_t (&G)[16], f32x4_t (&kr)[4], f32x16_t (&cur)[2], const f32x16_t (&pv)[2], auto first) {
+      constexpr bool SELECT = !decltype(first)::value && ABL != 1;
+      const float *nrow = &ktile[(t + 1) & 1][j * KLD + 8 * h];   // tile t+1
+      idx_base = (uint32_t)(r0 + (t - 1) * KT + 4 * h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { cur[0][r] = 0.f; cur[1][r] = 0.f; }
+      // staging: tile t+2 (requested two iterations ago) goes to LDS one 16-byte piece per k-step 0..3, over tile t's dead
+      // copy, and tile t+4 is requested right away into the same registers (loads and stores execute in program order).
+      // Both are unconditional: past the end of the segment the rows are clamped and the LDS copy is never read.
+      float *ldst = &ktile[t & 1][lrow * KLD + 4 * lc];
+      f32x4_t ks_[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) ks_[jj] = kr[jj];
+      gload(kr, r0 + (t + 4) * KT);
+#define MIVOS_SB __builtin_amdgcn_sched_barrier(0);
+#define MIVOS_HF(N, A, B) cur[(N) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, A), __builtin_bit_cast(half8_t, B), cur[(N) & 1], 0, 0, 0); MIVOS_SB
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (SELECT && ABL == 0 && (ks == 0 || ks == 4)) make_room();      // before the appends of scores 0-7 / 8-15
+        G[2 * ks] = *reinterpret_cast<const f32x4_t *>(nrow + 16 * ks); MIVOS_SB
+        MIVOS_HF(3 * ks, F[2 * ks + 1], qf[2 * ks])             // lo * hi
+        if (SELECT) slice_a(pv, 2 * ks);
+        MIVOS_SB
+        if (SELECT) slice_b(2 * ks);
+        MIVOS_SB
+        MIVOS_HF(3 * ks + 1, F[2 * ks], qf[2 * ks + 1])         // hi * lo
+        G[2 * ks + 1] = *reinterpret_cast<const f32x4_t *>(nrow + 16 * ks + 4); MIVOS_SB
+        if (SELECT) slice_a(pv, 2 * ks + 1);
+        MIVOS_SB
+        MIVOS_HF(3 * ks + 2, F[2 * ks], qf[2 * ks])             // hi * hi
+        if (SELECT) slice_b(2 * ks + 1);
+        MIVOS_SB
+        if (ks < 4) { *reinterpret_cast<f32x4_t *>(ldst + 32 * ks) = ks_[ks]; MIVOS_SB }
+      }
+#undef MIVOS_HF
+#undef MIVOS_SB
+      // ROCm 7.2's hazard recognizer leaves too few wait states between a v_mfma_f32_32x32x16_f16 and the first read of its
+      // result by the vector ALU when a branch or barrier lies between them (measured: stale last rows of the tile, i.e.
+      // dropped candidates); the operands tie every later use of these accumulators behind the wait
+      asm volatile("s_nop 15" : "+a"(cur[0]), "+a"(cur[1]));
+      if (ABL == 1) {                           // keep the MFMA results alive without selecting
+        const float sum = (cur[0][0] + cur[0][5]) + (cur[1][10] + cur[1][15]);
+        if (sum == 123.456f) a.lists[0] = 1ull;
+      }
+      __syncthreads();
+    };
+    tile_iter(0, fa, fb, krA, accA, accB, std::true_type{});
+    if (nt > 1) tile_iter(1, fb, fa, krB, accB, accA, std::false_type{});
+    for (int t = 2; t < nt; t += 2) {
+      tile_iter(t, fa, fb, krA, accA, accB, std::false_type{});
+      if (t + 1 < nt) tile_iter(t + 1, fb, fa, krB, accB, accA, std::false_type{});
+    }
+    // drain the pipeline: select on the last tile (the only one that can hold rows past the end of the memory)
+    const unsigned long long cfin = prof ? __builtin_readcyclecounter() : 0ull;
+    auto drain = [&](const f32x16_t (&last)[2]) {
+      const int pb = r0 + (nt - 1) * KT;
+      idx_base = (uint32_t)(pb + 4 * h);
+      f32x16_t masked[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = pb + 4 * h + 8 * (r >> 2) + (r & 3) < r1;
+        masked[0][r] = ok ? last[0][r] : -INFINITY;
+        masked[1][r] = ok ? last[1][r] : -INFINITY;
+      }
+      make_room();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { slice_a(masked, r); slice_b(r); }
+      make_room();
+#pragma unroll
+      for (int r = 8; r < 16; ++r) { slice_a(masked, r); slice_b(r); }
+    };
+    if (ABL != 1) {
+      if ((nt - 1) & 1) drain(accB);
+      else drain(accA);
+    }
+
+    // this segment's candidate lists: for each of the wave's 32 queries between min(n, k) and k + SLACK entries
+    for (int ql = 0; ql < QW2; ++ql) {
+      compact_one(ql, true);
+      wave_lds_handoff();
+      const int n0 = __builtin_amdgcn_readlane(my_cnt, ql), n1 = __builtin_amdgcn_readlane(my_cnt, ql + 32);
+      const int s = wave * QW2 + ql;
+      const uint64_t *src = cand + (wave * 2 * QW2 + ql) * REG2;   // region h at src + h * QW2 * REG2
+      uint64_t *dst = a.lists + (((long long)stream * a.slots + slot) * QT2 + s) * a.L;
+      if (lane < n0) dst[lane] = raw_to_key(src[lane]);
+      if (lane < n1) dst[n0 + lane] = raw_to_key(src[QW2 * REG2 + lane]);
+      for (int i = n0 + n1 + lane; i < a.L; i += 64) dst[i] = 0ull;
+    }
+    if (prof) clk_final += __builtin_readcyclecounter() - cfin;
+    t_begin += nt;
+  }
+  if (prof && tid == 0) {
+    a.dbg[0] = __builtin_readcyclecounter() - clk0;
+    a.dbg[1] = (unsigned long long)(t_end - (long long)blockIdx.x * a.tiles_per_wg);
+    a.dbg[2] = clk_room; a.dbg[3] = n_compact; a.dbg[4] = clk_final; a.dbg[5] = clk_pro;
+  }
+}
+
 // optional SH32 outputs of the readout (zero-bordered activation buffers of the LDS-DMA convolutions): raw and relu(raw),
 // addressed as image `obj`, pixel (q / q_width, q % q_width); strides in floats
 struct ShOut {
@@ -498,26 +787,28 @@ struct ShOut {
 // one single-wave workgroup per (object, query); __syncthreads() on a 64-thread block is just the LDS ordering fence
 // between the phases
 template <bool INDICES, int FIN_EPL>   // FIN_EPL: merged candidates per lane (64 FIN_EPL >= segments x L)
-__global__ __launch_bounds__(64) void memread_finalize_kernel(const uint64_t *__restrict__ lists,
+__global__ __launch_bounds__(64) void memread_finalize_kernel(const int *__restrict__ header,
                                                              const float *__restrict__ values, long long values_ostride,
                                                              float *__restrict__ out, long long out_ostride,
                                                              long long out_pstride, int32_t *__restrict__ idx_out,
-                                                             float *__restrict__ w_out, int n_q, int top_k, int n_qtiles,
-                                                             int tps, int tiles_per_wg, int slots, int L, ShOut sh) {
+                                                             float *__restrict__ w_out, int n_q, int top_k, ShOut sh) {
+  const uint64_t *__restrict__ lists = reinterpret_cast<const uint64_t *>(header + HEADER_BYTES / 4);
+  const int qt = header[0], n_qtiles = header[1], tps = header[2], tiles_per_wg = header[3], slots = header[4], L = header[5];
   __shared__ uint64_t sel[MAX_TOPK];
   __shared__ float wv[MAX_TOPK];
   __shared__ uint32_t oi[MAX_TOPK];
   __shared__ float ow[MAX_TOPK];
   const int lane = threadIdx.x;
   const int q = blockIdx.x, obj = blockIdx.y;
-  const int stream = obj * n_qtiles + q / QT, qs = q % QT;
+  const int stream = obj * n_qtiles + q / qt, qs = q % qt;
   // defined contents whatever the lists hold (ablation builds leave them incomplete): position 0, weight 0
   sel[lane] = pack_cand(-INFINITY, 0u); oi[lane] = 0u; ow[lane] = 0.f; wv[lane] = 0.f;
   __syncthreads();
   // the segments of this stream: workgroups w_first .. w_last of the select kernel
   const int w_first = (int)(((long long)stream * tps) / tiles_per_wg);
   const int w_last = (int)((((long long)stream + 1) * tps - 1) / tiles_per_wg);
-  const int n = (w_last - w_first + 1) * L;
+  int n = (w_last - w_first + 1) * L;
+  if (n > 64 * FIN_EPL) n = 64 * FIN_EPL;            // (never: the host sizes FIN_EPL for the larger of the two plans)
   uint64_t e[FIN_EPL];
 #pragma unroll
   for (int t = 0; t < FIN_EPL; ++t) {
@@ -525,7 +816,7 @@ __global__ __launch_bounds__(64) void memread_finalize_kernel(const uint64_t *__
     uint64_t v = 0ull;
     if (i < n) {
       const int sl = i / L, k = i - sl * L;
-      v = lists[(((long long)stream * slots + sl) * QT + qs) * L + k];
+      v = lists[(((long long)stream * slots + sl) * qt + qs) * L + k];
     }
     e[t] = v;
   }
@@ -625,7 +916,7 @@ __global__ __launch_bounds__(256) void split_keys_kernel(const float *__restrict
 
 // ---- host side --------------------------------------------------------------------------------------------------
 struct Plan {
-  int n_qtiles, streams, tps, n_wg, tiles_per_wg, slots, L;
+  int qt, n_qtiles, streams, tps, n_wg, tiles_per_wg, slots, L;
   long long total;
 };
 
@@ -641,9 +932,10 @@ static int compute_units() {
   return c;
 }
 
-static Plan make_plan(int n_obj, long long n_mem, int n_q, int top_k) {
+static Plan make_plan(int n_obj, long long n_mem, int n_q, int top_k, int qt) {
   Plan p;
-  p.n_qtiles = cdiv(n_q, QT);
+  p.qt = qt;
+  p.n_qtiles = cdiv(n_q, qt);
   p.streams = n_obj * p.n_qtiles;
   p.tps = cdiv(n_mem, KT);
   p.total = (long long)p.streams * p.tps;
@@ -661,37 +953,63 @@ static Plan make_plan(int n_obj, long long n_mem, int n_q, int top_k) {
   return p;
 }
 
+// which select kernel runs: the fp32 kernel and the 16-queries-per-wave fp16 kernel cut the queries into tiles of QT = 64,
+// the 32-queries-per-wave fp16 kernel (long memories) into tiles of QT2 = 128
+static std::atomic<long long> g_q128_min{-1};     // memory positions from which the 128-query plan is used (tests / tuning can move it)
+static long long q128_min() {
+  long long v = g_q128_min.load(std::memory_order_relaxed);
+  if (v < 0) {
+    v = getenv("MIVOS_MEMREAD_Q128_MIN") ? atoll(getenv("MIVOS_MEMREAD_Q128_MIN")) : 32768;
+    g_q128_min.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+static int select_qt(bool f16, long long n_mem) { return (f16 && n_mem >= q128_min()) ? QT2 : QT; }
+
+static long long lists_bytes(const Plan &p) { return (long long)p.streams * p.slots * p.qt * p.L * 8; }
+
 static int check_select_args(const float *keys, int64_t keys_ostride, const float *qk, int n_obj, int64_t n_mem, int n_q,
                              int top_k, void *workspace, int64_t workspace_bytes) {
   if (!keys || !qk || !workspace) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read: null pointer");
   if (top_k < 1 || top_k > MAX_TOPK) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read: top_k=%d unsupported (1..%d)", top_k, MAX_TOPK);
   if (n_obj < 1 || n_q < 1 || n_mem < 1 || n_mem >= 0x7fffffffLL) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read: bad sizes");
   if (n_mem < top_k) return fail(MIVOS_ERR_TOPK_RANGE, "selected index k out of range (top_k=%d > %lld memory positions)", top_k, (long long)n_mem);
-  if (((uintptr_t)keys & 15) || ((uintptr_t)qk & 15) || (keys_ostride & 3)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read: keys/qk must be 16-byte aligned");
+  if (((uintptr_t)keys & 15) || ((uintptr_t)qk & 15) || (keys_ostride & 3) || ((uintptr_t)workspace & 15))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read: keys/qk/workspace must be 16-byte aligned");
   if (workspace_bytes < mivos_memory_read_workspace_bytes(n_obj, n_mem, n_q, top_k)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read: workspace too small");
   return MIVOS_OK;
 }
 
 template <bool INDICES, int N>
-static void launch_finalize_n(const Plan &pl, void *workspace, const float *values, int64_t values_ostride, float *out, int64_t out_ostride,
+static void launch_finalize_n(void *workspace, const float *values, int64_t values_ostride, float *out, int64_t out_ostride,
                               int64_t out_pstride, int32_t *idx_out, float *w_out, int n_obj, int n_q, int top_k, hipStream_t st, const ShOut &sh) {
-  hipLaunchKernelGGL((memread_finalize_kernel<INDICES, N>), dim3(n_q, n_obj), dim3(64), 0, st, (const uint64_t *)workspace, values,
-                     (long long)values_ostride, out, (long long)out_ostride, (long long)out_pstride, idx_out, w_out, n_q, top_k,
-                     pl.n_qtiles, pl.tps, pl.tiles_per_wg, pl.slots, pl.L, sh);
+  hipLaunchKernelGGL((memread_finalize_kernel<INDICES, N>), dim3(n_q, n_obj), dim3(64), 0, st, (const int *)workspace, values,
+                     (long long)values_ostride, out, (long long)out_ostride, (long long)out_pstride, idx_out, w_out, n_q, top_k, sh);
 }
 
-static int launch_finalize(bool indices, const Plan &pl, void *workspace, const float *values, int64_t values_ostride, float *out,
-                           int64_t out_ostride, int64_t out_pstride, int32_t *idx_out, float *w_out, int n_obj, int n_q, int top_k,
+// The kernel reads the plan from the workspace header; the host only picks how many merged candidates a lane may hold, for
+// the larger of the plans a select call could have used with these sizes.
+static int launch_finalize(bool indices, void *workspace, const float *values, int64_t values_ostride, float *out,
+                           int64_t out_ostride, int64_t out_pstride, int32_t *idx_out, float *w_out, int n_obj, int64_t n_mem, int n_q, int top_k,
                            hipStream_t st, const ShOut &sh = ShOut{nullptr, nullptr, 0, 0, 0, 1}) {
-  const int per_lane = cdiv((long long)pl.slots * pl.L, 64);       // slots bounds the segments of any stream
+  const Plan p64 = make_plan(n_obj, n_mem, n_q, top_k, QT), p128 = make_plan(n_obj, n_mem, n_q, top_k, QT2);
+  const int slots = p64.slots > p128.slots ? p64.slots : p128.slots;
+  const int per_lane = cdiv((long long)slots * p64.L, 64);       // slots bounds the segments of any stream
 #define MIVOS_FIN(N)                                                                                                              \
-  (indices ? launch_finalize_n<true, N>(pl, workspace, values, values_ostride, out, out_ostride, out_pstride, idx_out, w_out, n_obj, n_q, top_k, st, sh) \
-           : launch_finalize_n<false, N>(pl, workspace, values, values_ostride, out, out_ostride, out_pstride, idx_out, w_out, n_obj, n_q, top_k, st, sh))
+  (indices ? launch_finalize_n<true, N>(workspace, values, values_ostride, out, out_ostride, out_pstride, idx_out, w_out, n_obj, n_q, top_k, st, sh) \
+           : launch_finalize_n<false, N>(workspace, values, values_ostride, out, out_ostride, out_pstride, idx_out, w_out, n_obj, n_q, top_k, st, sh))
   if (per_lane <= 4) MIVOS_FIN(4);
   else if (per_lane <= 8) MIVOS_FIN(8);
   else MIVOS_FIN(FIN_EPL_MAX);
 #undef MIVOS_FIN
   return check_launch("memread_finalize");
+}
+
+static int check_finalize_args(const char *what, int n_obj, int64_t n_mem, int n_q, int top_k, void *workspace, int64_t workspace_bytes) {
+  if (!workspace || ((uintptr_t)workspace & 15) || top_k < 1 || top_k > MAX_TOPK || n_obj < 1 || n_q < 1 || n_mem < top_k ||
+      workspace_bytes < mivos_memory_read_workspace_bytes(n_obj, n_mem, n_q, top_k))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "%s: arguments do not match the select call", what);
+  return MIVOS_OK;
 }
 
 }  // namespace mivos
@@ -700,25 +1018,34 @@ using namespace mivos;
 
 extern "C" int64_t mivos_memory_read_workspace_bytes(int n_obj, int64_t n_mem, int n_q, int top_k) {
   if (n_obj < 1 || n_q < 1 || n_mem < 1 || top_k < 1) return 0;
-  const Plan p = make_plan(n_obj, n_mem, n_q, top_k);
-  return (int64_t)p.streams * p.slots * QT * p.L * 8;
+  const long long a = lists_bytes(make_plan(n_obj, n_mem, n_q, top_k, QT)), b = lists_bytes(make_plan(n_obj, n_mem, n_q, top_k, QT2));
+  return HEADER_BYTES + (a > b ? a : b);
 }
 
-extern "C" int mivos_memory_read_plan(int n_obj, int64_t n_mem, int n_q, int top_k, int32_t *plan_out) {
+extern "C" int64_t mivos_memory_read_set_q128_min(int64_t n_mem_min) {
+  const long long old = q128_min();
+  if (n_mem_min >= 0) g_q128_min.store(n_mem_min, std::memory_order_relaxed);
+  return old;
+}
+
+extern "C" int mivos_memory_read_plan(int n_obj, int64_t n_mem, int n_q, int top_k, int f16x3, int32_t *plan_out) {
   if (!plan_out || n_obj < 1 || n_q < 1 || n_mem < 1 || top_k < 1) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read_plan: bad arguments");
-  const Plan p = make_plan(n_obj, n_mem, n_q, top_k);
+  const Plan p = make_plan(n_obj, n_mem, n_q, top_k, select_qt(f16x3 != 0, n_mem));
   plan_out[0] = p.n_wg; plan_out[1] = p.tiles_per_wg; plan_out[2] = p.slots; plan_out[3] = p.tps; plan_out[4] = p.streams; plan_out[5] = p.L;
+  plan_out[6] = p.qt;
   return MIVOS_OK;
 }
 
 static int launch_select(bool f16, const float *keys, int64_t keys_ostride, const float *qk, int n_obj, int64_t n_mem, int n_q, int top_k,
                          void *workspace, int64_t workspace_bytes, void *stream) {
   if (int rc = check_select_args(keys, keys_ostride, qk, n_obj, n_mem, n_q, top_k, workspace, workspace_bytes)) return rc;
-  const Plan pl = make_plan(n_obj, n_mem, n_q, top_k);
+  const int qt = select_qt(f16, n_mem);
+  const Plan pl = make_plan(n_obj, n_mem, n_q, top_k, qt);
   SelectArgs a;
-  a.keys = keys; a.keys_ostride = keys_ostride; a.qk = qk; a.lists = (uint64_t *)workspace; a.n_mem = n_mem; a.n_q = n_q;
+  a.keys = keys; a.keys_ostride = keys_ostride; a.qk = qk; a.header = (int *)workspace;
+  a.lists = (uint64_t *)((char *)workspace + HEADER_BYTES); a.n_mem = n_mem; a.n_q = n_q;
   a.top_k = top_k; a.n_qtiles = pl.n_qtiles; a.tps = pl.tps; a.total_tiles = pl.total; a.tiles_per_wg = pl.tiles_per_wg;
-  a.slots = pl.slots; a.L = pl.L;
+  a.slots = pl.slots; a.L = pl.L; a.qt = qt;
   static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;          // profiling only
   static const int dbg = getenv("MIVOS_MEMREAD_DBG") ? atoi(getenv("MIVOS_MEMREAD_DBG")) : 0;   // profiling only: prints cycles per tile
   static unsigned long long *dbg_buf = nullptr;
@@ -727,15 +1054,18 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
     if (!dbg_buf && hipMalloc((void **)&dbg_buf, 64) != hipSuccess) dbg_buf = nullptr;
     a.dbg = dbg_buf;
   }
-  // the wave-uniform skip of the append pays once most compares fail everywhere: long memories for the fp32 variant (whose
-  // appends cost issue slots next to the fp32 MFMAs anyway), earlier for the fp16 variant
+  // the wave-uniform skip of the append pays once most compares fail everywhere: long memories
   static const int br_min = getenv("MIVOS_MEMREAD_BR_MIN") ? atoi(getenv("MIVOS_MEMREAD_BR_MIN")) : 32768;   // tuning only
-  static const int br_min16 = getenv("MIVOS_MEMREAD_BR_MIN16") ? atoi(getenv("MIVOS_MEMREAD_BR_MIN16")) : 32768;   // tuning only
-  const bool br = n_mem >= (f16 ? br_min16 : br_min);
+  const bool br = n_mem >= br_min;
   const dim3 grid(pl.n_wg), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define MIVOS_SEL(ABL, BR, F16) hipLaunchKernelGGL((memread_select_kernel<ABL, BR, F16>), grid, block, 0, st, a)
-  if (f16) {
+#define MIVOS_SEL32(ABL, BR) hipLaunchKernelGGL((memread_select32_kernel<ABL, BR>), grid, block, 0, st, a)
+  if (qt == QT2) {
+    if (abl == 1) MIVOS_SEL32(1, false);
+    else if (br) MIVOS_SEL32(0, true);
+    else MIVOS_SEL32(0, false);
+  } else if (f16) {
     if (abl == 1) MIVOS_SEL(1, false, true);
     else if (br) MIVOS_SEL(0, true, true);
     else MIVOS_SEL(0, false, true);
@@ -745,13 +1075,15 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
     else MIVOS_SEL(0, false, false);
   }
 #undef MIVOS_SEL
+#undef MIVOS_SEL32
   if (dbg && dbg_buf) {
     unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(h, dbg_buf, 48, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[memread_select %s] n_obj=%d n_mem=%lld n_q=%d: workgroup 0 ran %llu tiles in %llu shader-clock ticks = %.0f per tile (MFMA issue alone: %d cycles); "
+    fprintf(stderr, "[memread_select %s q%d] n_obj=%d n_mem=%lld n_q=%d: workgroup 0 ran %llu tiles in %llu shader-clock ticks = %.0f per tile (MFMA issue alone: %d cycles); "
             "wave 0: %llu compactions in the loop = %llu ticks, segment prologues %llu, drains + final lists %llu\n",
-            f16 ? "f16x3" : "f32", n_obj, (long long)n_mem, n_q, h[1], h[0], h[1] ? (double)h[0] / (double)h[1] : 0.0, f16 ? 24 * 17 : 64 * 32, h[3], h[2], h[5], h[4]);
+            f16 ? "f16x3" : "f32", qt, n_obj, (long long)n_mem, n_q, h[1], h[0], h[1] ? (double)h[0] / (double)h[1] : 0.0,
+            qt == QT2 ? 24 * 32 : (f16 ? 24 * 17 : 64 * 32), h[3], h[2], h[5], h[4]);
   }
   return check_launch("memread_select");
 }
@@ -780,26 +1112,29 @@ extern "C" int mivos_memory_split_keys(const float *keys, int64_t keys_ostride, 
 extern "C" int mivos_memory_read_finalize(const float *values, int64_t values_ostride, float *out, int64_t out_ostride,
                                           int64_t out_pstride, int n_obj, int64_t n_mem, int n_q, int top_k, void *workspace,
                                           int64_t workspace_bytes, void *stream) {
-  if (!values || !out || !workspace || ((uintptr_t)values & 15) || ((uintptr_t)out & 15) || (out_pstride & 3) || (out_ostride & 3) || (values_ostride & 3))
+  if (!values || !out || ((uintptr_t)values & 15) || ((uintptr_t)out & 15) || (out_pstride & 3) || (out_ostride & 3) || (values_ostride & 3))
     return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read: values/out must be non-null and 16-byte aligned");
-  if (top_k < 1 || top_k > MAX_TOPK || n_mem < top_k || workspace_bytes < mivos_memory_read_workspace_bytes(n_obj, n_mem, n_q, top_k))
-    return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read_finalize: arguments do not match the select call");
-  const Plan pl = make_plan(n_obj, n_mem, n_q, top_k);
-  return launch_finalize(false, pl, workspace, values, values_ostride, out, out_ostride, out_pstride, nullptr, nullptr, n_obj, n_q,
+  if (int rc = check_finalize_args("memory_read_finalize", n_obj, n_mem, n_q, top_k, workspace, workspace_bytes)) return rc;
+  return launch_finalize(false, workspace, values, values_ostride, out, out_ostride, out_pstride, nullptr, nullptr, n_obj, n_mem, n_q,
                          top_k, (hipStream_t)stream);
 }
 
 extern "C" int mivos_memory_read_finalize_sh32(const float *values, int64_t values_ostride, void *raw_sh32, void *relu_sh32,
                                                int64_t a_nstride, int64_t a_rstride, int64_t a_pstride, int q_width, int n_obj,
                                                int64_t n_mem, int n_q, int top_k, void *workspace, int64_t workspace_bytes, void *stream) {
-  if (!values || !workspace || (!raw_sh32 && !relu_sh32) || ((uintptr_t)values & 15) || (values_ostride & 3) || q_width < 1 || n_q % q_width ||
+  if (!values || (!raw_sh32 && !relu_sh32) || ((uintptr_t)values & 15) || (values_ostride & 3) || q_width < 1 || n_q % q_width ||
       ((a_nstride | a_rstride | a_pstride) & 31) || ((uintptr_t)raw_sh32 & 127) || ((uintptr_t)relu_sh32 & 127))
     return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read_finalize_sh32: bad arguments");
-  if (top_k < 1 || top_k > MAX_TOPK || n_mem < top_k || workspace_bytes < mivos_memory_read_workspace_bytes(n_obj, n_mem, n_q, top_k))
-    return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read_finalize_sh32: arguments do not match the select call");
-  const Plan pl = make_plan(n_obj, n_mem, n_q, top_k);
+  if (int rc = check_finalize_args("memory_read_finalize_sh32", n_obj, n_mem, n_q, top_k, workspace, workspace_bytes)) return rc;
   const ShOut sh{(float *)raw_sh32, (float *)relu_sh32, a_nstride, a_rstride, a_pstride, q_width};
-  return launch_finalize(false, pl, workspace, values, values_ostride, nullptr, 0, 0, nullptr, nullptr, n_obj, n_q, top_k, (hipStream_t)stream, sh);
+  return launch_finalize(false, workspace, values, values_ostride, nullptr, 0, 0, nullptr, nullptr, n_obj, n_mem, n_q, top_k, (hipStream_t)stream, sh);
+}
+
+extern "C" int mivos_memory_read_finalize_indices(int32_t *idx_out, float *weight_out, int n_obj, int64_t n_mem, int n_q, int top_k,
+                                                  void *workspace, int64_t workspace_bytes, void *stream) {
+  if (!idx_out || !weight_out) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read_finalize_indices: null pointer");
+  if (int rc = check_finalize_args("memory_read_finalize_indices", n_obj, n_mem, n_q, top_k, workspace, workspace_bytes)) return rc;
+  return launch_finalize(true, workspace, nullptr, 0, nullptr, 0, 0, idx_out, weight_out, n_obj, n_mem, n_q, top_k, (hipStream_t)stream);
 }
 
 extern "C" int mivos_memory_read_topk(const float *keys, int64_t keys_ostride, const float *values, int64_t values_ostride,
@@ -814,17 +1149,6 @@ extern "C" int mivos_memory_read_topk(const float *keys, int64_t keys_ostride, c
 extern "C" int mivos_memory_read_topk_indices(const float *keys, int64_t keys_ostride, const float *qk, int32_t *idx_out,
                                               float *weight_out, int n_obj, int64_t n_mem, int n_q, int top_k,
                                               void *workspace, int64_t workspace_bytes, void *stream) {
-  if (!idx_out || !weight_out) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read_indices: null pointer");
   if (int rc = mivos_memory_read_select(keys, keys_ostride, qk, n_obj, n_mem, n_q, top_k, workspace, workspace_bytes, stream)) return rc;
-  const Plan pl = make_plan(n_obj, n_mem, n_q, top_k);
-  return launch_finalize(true, pl, workspace, nullptr, 0, nullptr, 0, 0, idx_out, weight_out, n_obj, n_q, top_k, (hipStream_t)stream);
-}
-
-extern "C" int mivos_memory_read_finalize_indices(int32_t *idx_out, float *weight_out, int n_obj, int64_t n_mem, int n_q, int top_k,
-                                                  void *workspace, int64_t workspace_bytes, void *stream) {
-  if (!idx_out || !weight_out || !workspace) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read_finalize_indices: null pointer");
-  if (top_k < 1 || top_k > MAX_TOPK || n_mem < top_k || workspace_bytes < mivos_memory_read_workspace_bytes(n_obj, n_mem, n_q, top_k))
-    return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read_finalize_indices: arguments do not match the select call");
-  const Plan pl = make_plan(n_obj, n_mem, n_q, top_k);
-  return launch_finalize(true, pl, workspace, nullptr, 0, nullptr, 0, 0, idx_out, weight_out, n_obj, n_q, top_k, (hipStream_t)stream);
+  return mivos_memory_read_finalize_indices(idx_out, weight_out, n_obj, n_mem, n_q, top_k, workspace, workspace_bytes, stream);
 }

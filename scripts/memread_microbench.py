@@ -33,24 +33,31 @@ for name, K, T, hw, topk, scale in CASES:
     ws = ops._workspace(lib.mivos_memory_read_workspace_bytes(K, n_mem, hw, topk), keys.device, "memread")
     st = ops._stream()
     ksplit = ops.split_keys(keys)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     ev[0].record()
     for _ in range(reps):
         check(lib.mivos_memory_read_select(keys.data_ptr(), n_mem * 128, q.data_ptr(), K, n_mem, hw, topk, ws.data_ptr(), ws.numel(), st))
     ev[1].record()
+    old_min = lib.mivos_memory_read_set_q128_min(1 << 40)          # 16 queries per wave
     for _ in range(reps):
         check(lib.mivos_memory_read_select_f16x3(ksplit.data_ptr(), n_mem * 128, q.data_ptr(), K, n_mem, hw, topk, ws.data_ptr(), ws.numel(), st))
     ev[2].record()
+    lib.mivos_memory_read_set_q128_min(0)                          # 32 queries per wave
+    for _ in range(reps):
+        check(lib.mivos_memory_read_select_f16x3(ksplit.data_ptr(), n_mem * 128, q.data_ptr(), K, n_mem, hw, topk, ws.data_ptr(), ws.numel(), st))
+    ev[3].record()
+    lib.mivos_memory_read_set_q128_min(old_min)
     for _ in range(reps):
         check(lib.mivos_memory_read_finalize(vals.data_ptr(), n_mem * 512, out.data_ptr(), out.stride(0), out.stride(1), K, n_mem, hw, topk,
                                              ws.data_ptr(), ws.numel(), st))
-    ev[3].record()
+    ev[4].record()
     torch.cuda.synchronize()
-    sel, sel16, fin = (ev[i].elapsed_time(ev[i + 1]) / reps for i in range(3))
+    sel, sel16, sel32, fin = (ev[i].elapsed_time(ev[i + 1]) / reps for i in range(4))
     fl = 2.0 * K * n_mem * hw * 128
     gather = 4.0 * 512 * K * hw * (topk + 1)
     print(f"{name:28s} select f32 {sel * 1e3:9.1f} us {fl / sel / 1e9:6.1f} TF/s ({fl / sel / 1e9 / 157.3 * 100:4.1f}% of f32 MFMA peak)   "
-          f"f16x3 {sel16 * 1e3:9.1f} us {fl / sel16 / 1e9:6.1f} TF/s ({3 * fl / sel16 / 1e9 / 2500 * 100:4.1f}% of 3-product fp16 peak, x{sel / sel16:4.2f})   "
+          f"f16x3 q64 {sel16 * 1e3:9.1f} us {fl / sel16 / 1e9:6.1f} TF/s ({3 * fl / sel16 / 1e9 / 2500 * 100:4.1f}% of 3-product fp16 peak, x{sel / sel16:4.2f})   "
+          f"q128 {sel32 * 1e3:9.1f} us {fl / sel32 / 1e9:6.1f} TF/s ({3 * fl / sel32 / 1e9 / 2500 * 100:4.1f}%, x{sel / sel32:4.2f})   "
           f"finalize {fin * 1e3:7.1f} us ({gather / fin / 1e6:6.0f} GB/s)", flush=True)
 
 if "--check" in sys.argv:
@@ -59,8 +66,9 @@ if "--check" in sys.argv:
     q = torch.randn(hw, 128, device=DEV) * 3
     aff = torch.einsum("kmc,qc->kmq", keys.double(), q.double() / (128 ** 0.5))
     ref = torch.topk(aff, topk, dim=1)[1].permute(0, 2, 1)
-    for mode in ("f32", "f16x3"):
-        ops.CONV_PRECISION = mode
+    for mode in ("f32", "f16x3", "f16x3-q128"):
+        ops.CONV_PRECISION = mode.split("-")[0]
+        lib.mivos_memory_read_set_q128_min(0 if mode.endswith("q128") else 1 << 40)
         idx, wgt = ops.memory_read_indices(keys, q, topk)
         same = (torch.sort(idx.long(), 2)[0] == torch.sort(ref, 2)[0]).all(2).float().mean()
         print(mode, "index sets equal to fp64 top-k:", float(same), " weights sum:", float(wgt.sum(2).mean()))

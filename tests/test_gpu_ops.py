@@ -51,6 +51,18 @@ def precision(request):
     ops.CONV_PRECISION = old
 
 
+@pytest.fixture(params=["f32", "f16x3", "f16x3-q128"])
+def mem_precision(request):
+    """The three affinity kernels of the memory read: exact fp32 MFMA, error-compensated fp16 MFMA with 16 queries per wave,
+    and with 32 queries per wave (the long-memory kernel, forced onto the small test shapes)."""
+    from mivos_amd import _lib
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, request.param.split("-")[0]
+    old_min = _lib.load().mivos_memory_read_set_q128_min(0 if request.param.endswith("q128") else 1 << 40)
+    yield request.param
+    ops.CONV_PRECISION = old
+    _lib.load().mivos_memory_read_set_q128_min(old_min)
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c[:8])))
 def test_conv2d_fused(case, precision):
     n, cin, cout, k, stride, pad, h, w, relu_in, relu_out, use_res, use_bn = case
@@ -336,7 +348,7 @@ def _run_mem(mk, mv, qk, top_k):
     return out.cpu().view(K, h, w, 512).permute(0, 3, 1, 2), idx.cpu(), wgt.cpu()
 
 
-def test_memory_read_golden(golden_dir, precision):
+def test_memory_read_golden(golden_dir, mem_precision):
     with np.load(os.path.join(golden_dir, "ops_small.npz")) as z:
         mk, mv, qk, ref = (torch.from_numpy(z[k]) for k in ("mr_mk", "mr_mv", "mr_qk", "mr_out"))
     got, _, _ = _run_mem(mk, mv, qk, 20)
@@ -347,7 +359,7 @@ def test_memory_read_golden(golden_dir, precision):
                                            (40, 8, 10, 1, 50),      # one 64-query stream cut into many segments (10 lists to merge)
                                            (7, 30, 54, 5, 50),      # the benchmark's shape: runs that cross stream boundaries
                                            (2, 68, 120, 1, 64)])    # 1080p grid, largest supported k
-def test_memory_read_vs_oracle(T, h, w, K, top_k, precision):
+def test_memory_read_vs_oracle(T, h, w, K, top_k, mem_precision):
     """Readout and exact top-k membership, for the exact fp32 MFMA affinity and for the error-compensated fp16 one (whose
     scores are as close to the exact product as torch's own fp32 ones: tests/test_host_logic.py).  A query whose k-th and (k+1)-th scores tie within fp32 rounding (the case
     T=23 holds one with a margin of exactly 0 in torch's own fp32 affinity) may legitimately resolve either way -
@@ -371,7 +383,7 @@ def test_memory_read_vs_oracle(T, h, w, K, top_k, precision):
         assert float((wgt[o].sum(1) - 1).abs().max()) < 1e-5
 
 
-def test_memory_read_sharp_scores_and_ties(precision):
+def test_memory_read_sharp_scores_and_ties(mem_precision):
     # large-magnitude keys (softmax nearly one-hot) and duplicated memory rows (exact score ties)
     mk, mv, qk = _mem_case(2, 8, 10, 1, seed=9, scale=6.0)
     mk[:, :, 1] = mk[:, :, 0]                                   # frame 1 duplicates frame 0: every score ties

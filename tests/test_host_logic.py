@@ -201,17 +201,19 @@ def test_tensor_util_matches_oracle():
 
 @pytest.mark.parametrize("n_obj,n_mem,n_q,top_k", [(5, 7 * 1620, 1620, 50), (1, 5 * 1620, 1620, 20), (3, 200 * 8160, 8160, 50),
                                                    (1, 80, 80, 20), (2, 160, 80, 20), (1, 24, 24, 20), (1, 1620, 1620, 50), (5, 15 * 1620, 1620, 50)])
-def test_memory_read_work_partition(n_obj, n_mem, n_q, top_k):
+@pytest.mark.parametrize("f16x3", [0, 1])
+def test_memory_read_work_partition(n_obj, n_mem, n_q, top_k, f16x3):
     """Host logic of the persistent memory-read kernel (csrc/memory_read.hip::make_plan): replay the kernel's segment
     loop for every workgroup and check that the tiles of every stream are covered exactly once, that the segment -> list
     slot mapping is a bijection onto 0..n-1 per stream and fits the allocated slots, and the finalize kernel's
     (w_first, w_last) formula names the same workgroups."""
     import ctypes as C
     lib = _lib.load()
-    out = (C.c_int32 * 6)()
-    assert lib.mivos_memory_read_plan(n_obj, n_mem, n_q, top_k, out) == 0
-    n_wg, per_wg, slots, tps, streams, L = list(out)
-    assert streams == n_obj * -(-n_q // 64) and tps == -(-n_mem // 32) and L == top_k + 16
+    out = (C.c_int32 * 7)()
+    assert lib.mivos_memory_read_plan(n_obj, n_mem, n_q, top_k, f16x3, out) == 0
+    n_wg, per_wg, slots, tps, streams, L, qt = list(out)
+    assert qt == (128 if f16x3 and n_mem >= 32768 else 64)          # 32 queries per wave for long memories (fp16 kernel)
+    assert streams == n_obj * -(-n_q // qt) and tps == -(-n_mem // 32) and L == top_k + 16
     total = streams * tps
     assert 1 <= n_wg <= 256 and (n_wg - 1) * per_wg < total <= n_wg * per_wg and slots <= 12
     covered = {s: [] for s in range(streams)}
@@ -232,7 +234,7 @@ def test_memory_read_work_partition(n_obj, n_mem, n_q, top_k):
         assert segs[0][0] == 0 and segs[-1][1] == tps and all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
         w_first, w_last = (s * tps) // per_wg, ((s + 1) * tps - 1) // per_wg
         assert used[s] == set(range(w_last - w_first + 1))
-    assert lib.mivos_memory_read_workspace_bytes(n_obj, n_mem, n_q, top_k) == streams * slots * 64 * L * 8
+    assert lib.mivos_memory_read_workspace_bytes(n_obj, n_mem, n_q, top_k) >= 64 + streams * slots * qt * L * 8       # 64-byte plan header
 
 
 def test_activation_batches_are_capped_by_bytes():
