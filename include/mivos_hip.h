@@ -184,7 +184,7 @@ int mivos_memory_read_topk(const float *keys, int64_t keys_ostride, const float 
  * first 64 bytes of the workspace, where the finalize kernels read it. */
 int mivos_memory_read_plan(int n_obj, int64_t n_mem, int n_q, int top_k, int f16x3, int32_t *plan_out);
 /* Tests / tuning: the bank depth (memory positions) from which mivos_memory_read_select_f16x3 uses its 128-queries-per-workgroup
- * kernel (default 32768, or the environment variable MIVOS_MEMREAD_Q128_MIN); returns the previous value, negative = only query. */
+ * kernel (default 400000, or the environment variable MIVOS_MEMREAD_Q128_MIN); returns the previous value, negative = only query. */
 int64_t mivos_memory_read_set_q128_min(int64_t n_mem_min);
 int mivos_memory_read_select(const float *keys, int64_t keys_ostride, const float *qk, int n_obj,
                              int64_t n_mem, int n_q, int top_k, void *workspace, int64_t workspace_bytes,

@@ -959,7 +959,9 @@ static std::atomic<long long> g_q128_min{-1};     // memory positions from which
 static long long q128_min() {
   long long v = g_q128_min.load(std::memory_order_relaxed);
   if (v < 0) {
-    v = getenv("MIVOS_MEMREAD_Q128_MIN") ? atoll(getenv("MIVOS_MEMREAD_Q128_MIN")) : 32768;
+    // measured (profiles/r02g_memread_microbench.txt): 1080p, 3 objects: 20 frames (163 k positions) 4.75 ms with 64 queries
+    // per workgroup vs 5.1 ms with 128 (smaller candidate regions, more compactions); 100 frames (816 k) 21.9 vs 18.9 ms
+    v = getenv("MIVOS_MEMREAD_Q128_MIN") ? atoll(getenv("MIVOS_MEMREAD_Q128_MIN")) : 400000;
     g_q128_min.store(v, std::memory_order_relaxed);
   }
   return v;
