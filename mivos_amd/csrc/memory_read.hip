@@ -44,6 +44,7 @@ constexpr int QW = 16;      // queries per wave (MFMA N)
 constexpr int QT = 64;      // queries per workgroup
 constexpr int KT = 32;      // memory positions per LDS tile (two 16-row MFMA sub-tiles)
 constexpr int KLD = 132;    // LDS pitch of a key row (floats)
+constexpr int STAGE_DEPTH = 4;   // key tiles in flight per workgroup on their way global -> registers -> LDS (16 VGPRs each)
 constexpr int REG = 61;                 // lane (q, g) appends to ITS region of REG entries: private fill level in a VGPR, no
                                         // atomics.  Regions are laid out [wave][g][q][REG]: the 16 lanes of a ds_write_b64 lane
                                         // group (same g, q = 0..15) are REG entries = 122 dwords apart, and with REG odd that
@@ -283,22 +284,31 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
           qreg[u] = v;
         }
       }
+      // the query fragments are finished HERE, before the key requests below go out: the compiler waits for its own loads
+      // with counts that do not know about those requests, so a later use would wait for the whole prefetch as well
+#pragma unroll
+      for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(qreg[u]));
     }
 
-    // global -> register staging of key tiles, two sets in flight (a tile is requested two iterations before it is
-    // written to LDS: one iteration, ~1 us, is shorter than the L2 latency when a dozen workgroups stream the same keys)
-    f32x4_t krA[4], krB[4];
-    auto gload = [&](f32x4_t (&kr)[4], int kb) {
-      // rows past the end of the segment are read from its first row instead: their scores are never selected (row < r1
-      // in slice_a), and touching the loaded values here (zero-filling) would make the wave wait for the load right away
+    // global -> register -> LDS staging of key tiles, STAGE_DEPTH register sets in flight: a tile is requested STAGE_DEPTH
+    // iterations before it is written to LDS.  What bounds the tile loop is the rate at which a CU can pull its 16 KB per tile
+    // through the L2 (scripts/ubench/mfma_f16_tile.hip: with two tiles in flight 0.40 - 0.67 us per tile, more than the MFMAs
+    // take), i.e. latency x bytes in flight.  The requests are inline assembly on purpose: the compiler's vmcnt bookkeeping
+    // loses the order of loads carried around the loop and waits for the NEWEST request whenever the oldest is needed
+    // (measured: one tile in flight); here nothing is tracked and the wait is written out (requests complete in order).
+    f32x4_t kr[STAGE_DEPTH][4];
+    auto gload = [&](f32x4_t (&krs)[4], int kb) {
+      // rows past the end of the segment are read from its first row instead (always a valid address): their scores are
+      // never selected, and the request count per iteration stays constant, which the explicit vmcnt below relies on
       const int m = kb + lrow;
       const f32x4_t *src = reinterpret_cast<const f32x4_t *>(kbase + (long long)(m < r1 ? m : r0) * CK) + lc;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) kr[jj] = src[8 * jj];
+      asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:128\n\t"
+                   "global_load_dwordx4 %2, %4, off offset:256\n\tglobal_load_dwordx4 %3, %4, off offset:384"
+                   : "=&v"(krs[0]), "=&v"(krs[1]), "=&v"(krs[2]), "=&v"(krs[3]) : "v"(src) : "memory");
     };
-    auto lds_store = [&](f32x4_t (&kr)[4], int buf) {
+    auto lds_store = [&](f32x4_t (&krs)[4], int buf) {
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4_t *>(&ktile[buf][lrow * KLD + 4 * (lc + 8 * jj)]) = kr[jj];
+      for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4_t *>(&ktile[buf][lrow * KLD + 4 * (lc + 8 * jj)]) = krs[jj];
     };
 
     // scores of the previous tile (software pipeline): -inf = nothing to select on the first tile
@@ -377,12 +387,13 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
     // ds_read_b128 per 8 MFMAs) instead of in one burst after the barrier; tile t+2 is then written over tile t's LDS copy
     // (dead once every wave holds it in registers), so two LDS buffers suffice and there is one barrier per tile.
     f32x4_t fa0[8], fa1[8], fb0[8], fb1[8];
-    gload(krA, r0);
-    if (nt > 1) gload(krB, r0 + KT);
-    lds_store(krA, 0);
-    if (nt > 1) lds_store(krB, 1);
-    if (nt > 2) gload(krA, r0 + 2 * KT);
-    if (nt > 3) gload(krB, r0 + 3 * KT);
+    gload(kr[0], r0);
+    gload(kr[1], r0 + KT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_store(kr[0], 0);
+    lds_store(kr[1], 1);
+#pragma unroll
+    for (int d = 0; d < STAGE_DEPTH; ++d) gload(kr[d], r0 + (2 + d) * KT);     // set d: tiles 2 + d, 2 + d + STAGE_DEPTH, ...
     __syncthreads();
     {
       const float *arow0 = &ktile[0][jq * KLD + coff];
@@ -397,8 +408,12 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
     if (prof) clk_pro += __builtin_readcyclecounter() - cpro;
     // one tile: MFMAs on fragment set F (tile t) while G receives tile t+1's fragments and tile t-1's scores are selected
     auto tile_iter = [&](int t, f32x4_t (&F0)[8], f32x4_t (&F1)[8], f32x4_t (&G0)[8], f32x4_t (&G1)[8], f32x4_t (&kr)[4]) {
-      if (t + 2 < nt) lds_store(kr, t & 1);           // tile t+2 (requested in iteration t-2) over tile t's (dead) LDS copy
-      if (t + 4 < nt) gload(kr, r0 + (t + 4) * KT);
+      // tile t+2 (requested STAGE_DEPTH iterations ago: everything but the STAGE_DEPTH - 1 younger sets has landed) goes over
+      // tile t's dead LDS copy, its registers take the request for tile t + 2 + STAGE_DEPTH.  Unconditional: past the end of
+      // the segment the rows are clamped and the LDS copy is never read.
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (STAGE_DEPTH - 1)) : "memory");
+      lds_store(kr, t & 1);
+      gload(kr, r0 + (t + 2 + STAGE_DEPTH) * KT);
       if (ABL == 0) make_room();
       const float *nrow0 = &ktile[(t + 1) & 1][jq * KLD + coff];   // tile t+1 (stale data past the segment's end: unused)
       f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -465,10 +480,14 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
       }
       __syncthreads();
     };
-    for (int t = 0; t < nt; t += 2) {
-      tile_iter(t, fa0, fa1, fb0, fb1, krA);
-      if (t + 1 < nt) tile_iter(t + 1, fb0, fb1, fa0, fa1, krB);
+    static_assert(STAGE_DEPTH == 4, "the tile loop is unrolled for four staging sets");
+    for (int t = 0; t < nt; t += 4) {
+      tile_iter(t, fa0, fa1, fb0, fb1, kr[0]);
+      if (t + 1 < nt) tile_iter(t + 1, fb0, fb1, fa0, fa1, kr[1]);
+      if (t + 2 < nt) tile_iter(t + 2, fa0, fa1, fb0, fb1, kr[2]);
+      if (t + 3 < nt) tile_iter(t + 3, fb0, fb1, fa0, fa1, kr[3]);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the requests past the end of the segment: their registers are reused
     // drain the pipeline: select on the last tile
     const unsigned long long cfin = prof ? __builtin_readcyclecounter() : 0ull;
     make_room();
@@ -595,18 +614,23 @@ __global__ __launch_bounds__(256, 1) void memread_select32_kernel(const SelectAr
         qf[2 * ks] = __builtin_bit_cast(f32x4_t, hi);
         qf[2 * ks + 1] = __builtin_bit_cast(f32x4_t, lo);
       }
+#pragma unroll
+      for (int x = 0; x < 16; ++x) asm volatile("" : "+v"(qf[x]));      // finished before the key requests go out
     }
 
-    f32x4_t krA[4], krB[4];
-    auto gload = [&](f32x4_t (&kr)[4], int kb) {
+    // global -> register -> LDS staging, STAGE_DEPTH tiles in flight, requests in inline assembly with explicit vmcnt (see
+    // memread_select_kernel)
+    f32x4_t kr[STAGE_DEPTH][4];
+    auto gload = [&](f32x4_t (&krs)[4], int kb) {
       const int m = kb + lrow;                        // rows past the segment's end: its first row instead (never selected)
       const f32x4_t *src = reinterpret_cast<const f32x4_t *>(kbase + (long long)(m < r1 ? m : r0) * CK) + lc;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) kr[jj] = src[8 * jj];
+      asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:128\n\t"
+                   "global_load_dwordx4 %2, %4, off offset:256\n\tglobal_load_dwordx4 %3, %4, off offset:384"
+                   : "=&v"(krs[0]), "=&v"(krs[1]), "=&v"(krs[2]), "=&v"(krs[3]) : "v"(src) : "memory");
     };
-    auto lds_store = [&](f32x4_t (&kr)[4], int buf) {
+    auto lds_store = [&](f32x4_t (&krs)[4], int buf) {
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4_t *>(&ktile[buf][lrow * KLD + 4 * (lc + 8 * jj)]) = kr[jj];
+      for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4_t *>(&ktile[buf][lrow * KLD + 4 * (lc + 8 * jj)]) = krs[jj];
     };
 
     float my_tau = -INFINITY;
@@ -656,12 +680,13 @@ __global__ __launch_bounds__(256, 1) void memread_select32_kernel(const SelectAr
 
     const unsigned long long cpro = prof ? __builtin_readcyclecounter() : 0ull;
     f32x4_t fa[16], fb[16];
-    gload(krA, r0);
-    if (nt > 1) gload(krB, r0 + KT);
-    lds_store(krA, 0);
-    if (nt > 1) lds_store(krB, 1);
-    if (nt > 2) gload(krA, r0 + 2 * KT);
-    if (nt > 3) gload(krB, r0 + 3 * KT);
+    gload(kr[0], r0);
+    gload(kr[1], r0 + KT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_store(kr[0], 0);
+    lds_store(kr[1], 1);
+#pragma unroll
+    for (int d = 0; d < STAGE_DEPTH; ++d) gload(kr[d], r0 + (2 + d) * KT);     // set d: tiles 2 + d, 2 + d + STAGE_DEPTH, ...
     __syncthreads();
     {
       const float *arow = &ktile[0][j * KLD + 8 * h];
@@ -678,20 +703,17 @@ __global__ __launch_bounds__(256, 1) void memread_select32_kernel(const SelectAr
     // t+2 goes from its staging registers to LDS (over tile t's dead copy), tile t+4 is requested, and tile t-1's scores
     // (accumulator set `pv`) are selected.  Everything is dealt out between the MFMAs, pinned by scheduling barriers.
     f32x16_t accA[2], accB[2];
-    auto tile_iter = [&](int t, f32x4_t (&F)[16], f32x4_t (&G)[16], f32x4_t (&kr)[4], f32x16_t (&cur)[2], const f32x16_t (&pv)[2], auto first) {
+    auto tile_iter = [&](int t, f32x4_t (&F)[16], f32x4_t (&G)[16], f32x4_t (&krs)[4], f32x16_t (&cur)[2], const f32x16_t (&pv)[2], auto first) {
       constexpr bool SELECT = !decltype(first)::value && ABL != 1;
       const float *nrow = &ktile[(t + 1) & 1][j * KLD + 8 * h];   // tile t+1
       idx_base = (uint32_t)(r0 + (t - 1) * KT + 4 * h);
 #pragma unroll
       for (int r = 0; r < 16; ++r) { cur[0][r] = 0.f; cur[1][r] = 0.f; }
-      // staging: tile t+2 (requested two iterations ago) goes to LDS one 16-byte piece per k-step 0..3, over tile t's dead
-      // copy, and tile t+4 is requested right away into the same registers (loads and stores execute in program order).
-      // Both are unconditional: past the end of the segment the rows are clamped and the LDS copy is never read.
+      // staging: tile t+2 (requested STAGE_DEPTH iterations ago) goes to LDS one 16-byte piece per k-step 0..3, over tile t's
+      // dead copy; then its registers take the request for tile t + 2 + STAGE_DEPTH.  Both are unconditional: past the end of
+      // the segment the rows are clamped and the LDS copy is never read.
       float *ldst = &ktile[t & 1][lrow * KLD + 4 * lc];
-      f32x4_t ks_[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) ks_[jj] = kr[jj];
-      gload(kr, r0 + (t + 4) * KT);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (STAGE_DEPTH - 1)) : "memory");
 #define MIVOS_SB __builtin_amdgcn_sched_barrier(0);
 #define MIVOS_HF(N, A, B) cur[(N) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, A), __builtin_bit_cast(half8_t, B), cur[(N) & 1], 0, 0, 0); MIVOS_SB
 #pragma unroll
@@ -710,7 +732,8 @@ __global__ __launch_bounds__(256, 1) void memread_select32_kernel(const SelectAr
         MIVOS_HF(3 * ks + 2, F[2 * ks], qf[2 * ks])             // hi * hi
         if (SELECT) slice_b(2 * ks + 1);
         MIVOS_SB
-        if (ks < 4) { *reinterpret_cast<f32x4_t *>(ldst + 32 * ks) = ks_[ks]; MIVOS_SB }
+        if (ks < 4) { *reinterpret_cast<f32x4_t *>(ldst + 32 * ks) = krs[ks]; MIVOS_SB }
+        if (ks == 3) { gload(krs, r0 + (t + 2 + STAGE_DEPTH) * KT); MIVOS_SB }
       }
 #undef MIVOS_HF
 #undef MIVOS_SB
@@ -724,12 +747,17 @@ __global__ __launch_bounds__(256, 1) void memread_select32_kernel(const SelectAr
       }
       __syncthreads();
     };
-    tile_iter(0, fa, fb, krA, accA, accB, std::true_type{});
-    if (nt > 1) tile_iter(1, fb, fa, krB, accB, accA, std::false_type{});
-    for (int t = 2; t < nt; t += 2) {
-      tile_iter(t, fa, fb, krA, accA, accB, std::false_type{});
-      if (t + 1 < nt) tile_iter(t + 1, fb, fa, krB, accB, accA, std::false_type{});
+    tile_iter(0, fa, fb, kr[0], accA, accB, std::true_type{});
+    if (nt > 1) tile_iter(1, fb, fa, kr[1], accB, accA, std::false_type{});
+    if (nt > 2) tile_iter(2, fa, fb, kr[2], accA, accB, std::false_type{});
+    if (nt > 3) tile_iter(3, fb, fa, kr[3], accB, accA, std::false_type{});
+    for (int t = 4; t < nt; t += 4) {
+      tile_iter(t, fa, fb, kr[0], accA, accB, std::false_type{});
+      if (t + 1 < nt) tile_iter(t + 1, fb, fa, kr[1], accB, accA, std::false_type{});
+      if (t + 2 < nt) tile_iter(t + 2, fa, fb, kr[2], accA, accB, std::false_type{});
+      if (t + 3 < nt) tile_iter(t + 3, fb, fa, kr[3], accB, accA, std::false_type{});
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the requests past the end of the segment: their registers are reused
     // drain the pipeline: select on the last tile (the only one that can hold rows past the end of the memory)
     const unsigned long long cfin = prof ? __builtin_readcyclecounter() : 0ull;
     auto drain = [&](const f32x16_t (&last)[2]) {
