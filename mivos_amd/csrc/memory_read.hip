@@ -44,6 +44,7 @@ constexpr int QW = 16;      // queries per wave (MFMA N)
 constexpr int QT = 64;      // queries per workgroup
 constexpr int KT = 32;      // memory positions per LDS tile (two 16-row MFMA sub-tiles)
 constexpr int KLD = 132;    // LDS pitch of a key row (floats)
+constexpr int STAGE_DEPTH2 = 4;  // ... of the 32-queries-per-wave kernel (its tile loop is written out for four sets)
 constexpr int STAGE_DEPTH = 4;   // key tiles in flight per workgroup on their way global -> registers -> LDS (16 VGPRs each)
 constexpr int REG = 61;                 // lane (q, g) appends to ITS region of REG entries: private fill level in a VGPR, no
                                         // atomics.  Regions are laid out [wave][g][q][REG]: the 16 lanes of a ds_write_b64 lane
@@ -480,12 +481,15 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
       }
       __syncthreads();
     };
-    static_assert(STAGE_DEPTH == 4, "the tile loop is unrolled for four staging sets");
-    for (int t = 0; t < nt; t += 4) {
-      tile_iter(t, fa0, fa1, fb0, fb1, kr[0]);
-      if (t + 1 < nt) tile_iter(t + 1, fb0, fb1, fa0, fa1, kr[1]);
-      if (t + 2 < nt) tile_iter(t + 2, fa0, fa1, fb0, fb1, kr[2]);
-      if (t + 3 < nt) tile_iter(t + 3, fb0, fb1, fa0, fa1, kr[3]);
+    static_assert(STAGE_DEPTH % 2 == 0, "fragment sets alternate with the tile parity");
+    for (int t = 0; t < nt; t += STAGE_DEPTH) {
+#pragma unroll
+      for (int d = 0; d < STAGE_DEPTH; ++d) {         // unrolled: staging set d and the fragment ping-pong are compile-time
+        if (t + d < nt) {
+          if (d & 1) tile_iter(t + d, fb0, fb1, fa0, fa1, kr[d]);
+          else tile_iter(t + d, fa0, fa1, fb0, fb1, kr[d]);
+        }
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the requests past the end of the segment: their registers are reused
     // drain the pipeline: select on the last tile
@@ -618,9 +622,9 @@ __global__ __launch_bounds__(256, 1) void memread_select32_kernel(const SelectAr
       for (int x = 0; x < 16; ++x) asm volatile("" : "+v"(qf[x]));      // finished before the key requests go out
     }
 
-    // global -> register -> LDS staging, STAGE_DEPTH tiles in flight, requests in inline assembly with explicit vmcnt (see
+    // global -> register -> LDS staging, STAGE_DEPTH2 tiles in flight, requests in inline assembly with explicit vmcnt (see
     // memread_select_kernel)
-    f32x4_t kr[STAGE_DEPTH][4];
+    f32x4_t kr[STAGE_DEPTH2][4];
     auto gload = [&](f32x4_t (&krs)[4], int kb) {
       const int m = kb + lrow;                        // rows past the segment's end: its first row instead (never selected)
       const f32x4_t *src = reinterpret_cast<const f32x4_t *>(kbase + (long long)(m < r1 ? m : r0) * CK) + lc;
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(256, 1) void memread_select32_kernel(const SelectAr
     lds_store(kr[0], 0);
     lds_store(kr[1], 1);
 #pragma unroll
-    for (int d = 0; d < STAGE_DEPTH; ++d) gload(kr[d], r0 + (2 + d) * KT);     // set d: tiles 2 + d, 2 + d + STAGE_DEPTH, ...
+    for (int d = 0; d < STAGE_DEPTH2; ++d) gload(kr[d], r0 + (2 + d) * KT);     // set d: tiles 2 + d, 2 + d + STAGE_DEPTH2, ...
     __syncthreads();
     {
       const float *arow = &ktile[0][j * KLD + 8 * h];
@@ -709,11 +713,11 @@ __global__ __launch_bounds__(256, 1) void memread_select32_kernel(const SelectAr
       idx_base = (uint32_t)(r0 + (t - 1) * KT + 4 * h);
 #pragma unroll
       for (int r = 0; r < 16; ++r) { cur[0][r] = 0.f; cur[1][r] = 0.f; }
-      // staging: tile t+2 (requested STAGE_DEPTH iterations ago) goes to LDS one 16-byte piece per k-step 0..3, over tile t's
-      // dead copy; then its registers take the request for tile t + 2 + STAGE_DEPTH.  Both are unconditional: past the end of
+      // staging: tile t+2 (requested STAGE_DEPTH2 iterations ago) goes to LDS one 16-byte piece per k-step 0..3, over tile t's
+      // dead copy; then its registers take the request for tile t + 2 + STAGE_DEPTH2.  Both are unconditional: past the end of
       // the segment the rows are clamped and the LDS copy is never read.
       float *ldst = &ktile[t & 1][lrow * KLD + 4 * lc];
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (STAGE_DEPTH - 1)) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (STAGE_DEPTH2 - 1)) : "memory");
 #define MIVOS_SB __builtin_amdgcn_sched_barrier(0);
 #define MIVOS_HF(N, A, B) cur[(N) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, A), __builtin_bit_cast(half8_t, B), cur[(N) & 1], 0, 0, 0); MIVOS_SB
 #pragma unroll
@@ -733,7 +737,7 @@ __global__ __launch_bounds__(256, 1) void memread_select32_kernel(const SelectAr
         if (SELECT) slice_b(2 * ks + 1);
         MIVOS_SB
         if (ks < 4) { *reinterpret_cast<f32x4_t *>(ldst + 32 * ks) = krs[ks]; MIVOS_SB }
-        if (ks == 3) { gload(krs, r0 + (t + 2 + STAGE_DEPTH) * KT); MIVOS_SB }
+        if (ks == 3) { gload(krs, r0 + (t + 2 + STAGE_DEPTH2) * KT); MIVOS_SB }
       }
 #undef MIVOS_HF
 #undef MIVOS_SB
