@@ -5,7 +5,7 @@ O=$R/gpurun_out
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum; do
   rm -rf /tmp/pm_$c
-  timeout 300 rocprofv3 --pmc $c -d /tmp/pm_$c --output-format csv -- python $R/scripts/tmp/memread_case.py 3 100 8160 50 q64 q128 > /dev/null 2> /tmp/pm_$c.err
+  timeout 300 rocprofv3 --pmc $c -d /tmp/pm_$c --output-format csv -- python $R/scripts/memread_case.py 3 100 8160 50 q64 q128 > /dev/null 2> /tmp/pm_$c.err
   f=$(find /tmp/pm_$c -name "*counter_collection.csv" | head -1)
   python - "$f" $c <<'PY'
 import csv, sys, collections

@@ -1,6 +1,6 @@
 """One memory-read shape, the select kernels launched a few times each (profiler target): K T hw topk"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mivos_amd import _lib, ops
 from mivos_amd._lib import check

@@ -1,5 +1,8 @@
+"""Exact top-k membership of the fp16 select kernels against a torch fp64 top-k on one shape (T h w K top_k), with the
+missing / extra positions of the first failing queries (tile, row) - the tool that located the MFMA read hazard.
+   python scripts/memread_check.py 23 30 54 1 50        (MIVOS_MEMREAD_BR_MIN=1 forces the branchy append)"""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mivos_amd import _lib, ops
 torch.set_grad_enabled(False)
