@@ -166,7 +166,7 @@ def kernel_rooflines(samples, overhead=0.0):
         ach = flops / secs / 1e12
         f16 = ops_precision() == "f16x3"
         peak = F16X3_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS
-        aff = dict(bound="mfma", kernel="memread_select_kernel<F16> (error-compensated fp16 MFMA affinity on pre-split keys + streaming top-k)" if f16
+        aff = dict(bound="mfma", kernel="memread_select_kernel<F16> / memread_select32_kernel from 400 k memory positions (error-compensated fp16 MFMA affinity on pre-split keys + streaming top-k)" if f16
                    else "memread_select_kernel (exact fp32 MFMA affinity + streaming top-k)",
                    achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
                    frac_of_f32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
