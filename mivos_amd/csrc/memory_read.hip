@@ -1,26 +1,26 @@
-// Space-time memory read for gfx950: exact-fp32 MFMA affinity tiles + streaming per-query top-k in LDS + softmax over
-// the k survivors + sparse value readout.  The [T*H*W x H*W] affinity of the reference (prop_net.py:85-88, 52 MB/object
-// at 480p T=5, 160 GB at 1080p T=200) is never materialised.
+// Space-time memory read for gfx950: MFMA affinity tiles (error-compensated fp16, or exact fp32) + streaming per-query
+// top-k in LDS + softmax over the k survivors + sparse value readout.  The [T*H*W x H*W] affinity of the reference
+// (prop_net.py:85-88, 52 MB/object at 480p T=5, 160 GB at 1080p T=200) is never materialised.
 //
-// Kernel 1 (memread_select): PERSISTENT, one 4-wave workgroup per CU (one wave per SIMD, 154 KB of LDS).
+// Kernel 1 (memread_select): PERSISTENT, one 4-wave workgroup per CU (one wave per SIMD, 155 KB of LDS).
 //   Work = streams x tiles: a stream is (object, tile of 64 queries) against the whole memory, cut into tiles of 32
 //   memory positions.  The streams' tiles are laid end to end and dealt to the workgroups in equal contiguous runs
 //   (stream-K style): perfect balance for any object count / frame size / bank depth, and a run that crosses a stream
 //   boundary is processed as two segments.  Every segment leaves its own candidate list (>= its exact top-k) in the
-//   workspace; kernel 2 merges the 1-3 lists of a query exactly.
-//   Per wave: 16 queries (pre-scaled by 1/sqrt(128)) live in 32 VGPRs as the MFMA B operand; key tiles are staged in
-//   LDS once per workgroup (double buffered, one barrier per tile, 528-byte row pitch => conflict-free ds_read_b128);
-//   2 x 32 v_mfma_f32_16x16x4_f32 (two independent accumulators: rows 0-15 / 16-31 of the tile) give the 32x16 score
-//   tile; lane (j, g) owns 8 scores of query j.
-//   Selection runs IN THE SHADOW of the next tile's MFMAs, in the same wave: measured in round 1
-//   (scripts/ubench/lds_vs_mfma.hip) a co-resident wave gets ~1 vector instruction issued per MFMA of its partner,
-//   while a wave's own independent instructions issue freely between its MFMAs (7 slots per 32-cycle MFMA).  So the
-//   loop is software pipelined: the 8 score registers of tile t-1 are compared / appended one per group of 8 MFMAs of
-//   tile t, the LDS atomic that reserves the slots is issued one group before its result is needed.
-//   Candidates: per query 240 packed {orderable score, ~index} entries in LDS.  Scores above the query's threshold tau
-//   are appended; when a buffer may overflow the owning wave compacts it: bisection of the packed 64-bit keys (all
-//   distinct) with two ballots per bit, stopped as soon as between k and k+16 entries survive (an exact cut is not
-//   needed until the end), tau := the cut.  Ties: lower memory index wins (torch.topk leaves ties unspecified).
+//   workspace; kernel 2 merges the lists of a query exactly (the select launch leaves its plan in the workspace header).
+//   Per wave: 16 queries (pre-scaled by 1/sqrt(128)) live in 32 VGPRs as the MFMA B operand; key tiles go global ->
+//   registers -> LDS once per workgroup (four tiles in flight, requests in inline assembly with an explicit vmcnt; two LDS
+//   buffers, one barrier per tile, 528-byte row pitch => conflict-free ds_read_b128; the fragments of tile t+1 are read
+//   into a second register set during tile t); the MFMAs of a tile give the 32x16 score tile on two accumulators (rows
+//   0-15 / 16-31); lane (j, g) owns 8 scores of query j.
+//   Selection is software pipelined: the 8 score registers of tile t-1 are compared / appended between the MFMAs of tile
+//   t.  (Beside fp32 MFMAs nothing a wave issues is hidden - measured, scripts/ubench/README.md - so the append path is
+//   as short as it can be: compare, index, address, one exec-masked ds_write2_b32, fill level; beside fp16 MFMAs it is.)
+//   Candidates: lane (q, g) appends raw {score bits, index} entries to ITS region of REG entries of query q's buffer
+//   (private fill level in a VGPR: no atomics).  When a region may overflow the owning wave compacts the query's four
+//   regions: entries -> orderable keys {score, ~index}, bisection (common high bits skipped, score words first) stopped as
+//   soon as between k and k+16 entries survive (an exact cut is not needed until the end), survivors dealt back round
+//   robin, tau := the cut.  Ties: lower memory index wins (torch.topk leaves ties unspecified).
 //   F16 variant (the engine's default precision, "f16x3"): the same kernel with the affinity on the fp16 matrix pipe, error
 //   compensated like the convolutions: keys and queries are split x = hi + lo (two fp16, 22 significant bits), a k-step of
 //   32 channels is three v_mfma_f32_16x16x32_f16 (lo*hi + hi*lo + hi*hi, fp32 accumulate; the lo*lo term is below fp32
