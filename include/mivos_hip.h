@@ -156,6 +156,31 @@ int mivos_maxpool3x3s2_sh32(const float *x, void *y_sh32, int64_t y_nstride, int
 int mivos_tap_sum9(const float *t, const float *bias, float *out, int N, int H, int W, void *stream);
 
 /* --------------------------------------------------------------------------------------------
+ * FusionNet.forward (model/fusion_net.py:32-50; called per object and frame from inference_core.py:202-217) as one call:
+ * x16 [batch][H][W][16] = the channel concatenation of fusion_net.py:38 (im 3, seg1, seg2, attn 2, time 2, 7 zero channels;
+ * mivos_interleave_planes builds it) -> logits [batch][H][W] (the caller applies the sigmoid, inference_core.py:214).
+ * layer[0..4] = conv1[0], conv2[0], conv2[2], conv3[0], conv3[2] (3x3), layer[5] = the 1x1 projection of final_conv to its
+ * nine tap products (16 output channels, rows 0..8 = the taps); every layer as the precision-1 operands of
+ * mivos_conv2d_fused (w16 from mivos_pack_weights_f16x3, scale16 = 2^-s per output channel, bias or NULL).
+ * A host-side composition of mivos_conv2d_fused / mivos_tap_sum9 launches on `stream` (bit-identical to issuing them one by
+ * one); scratch: mivos_fusion_net_scratch_floats() floats of device memory; workspace: optional split-K scratch.
+ * -------------------------------------------------------------------------------------------- */
+typedef struct { const void *w16; const float *scale16; const float *bias; } mivos_fusion_layer;
+typedef struct {
+  mivos_fusion_layer layer[6];
+  const float *final_bias;     /* final_conv.bias (one float) or NULL */
+  const float *x16;
+  float *logits;
+  float *scratch;
+  int64_t scratch_floats;
+  int32_t batch, height, width;
+  void *workspace;
+  int64_t workspace_bytes;
+} mivos_fusion_net_desc;
+int64_t mivos_fusion_net_scratch_floats(int batch, int height, int width);
+int mivos_fusion_net_forward(const mivos_fusion_net_desc *d, void *stream);
+
+/* --------------------------------------------------------------------------------------------
  * Space-time memory read: affinity (MFMA) -> streaming per-query top-k -> softmax over the k
  * survivors -> sparse value readout.  Replaces EvalMemoryReader.forward + softmax_w_g_top
  * (prop_net.py:47-63, 81-108) without materialising the [THW x HW] affinity.

@@ -31,12 +31,26 @@ class InterleaveDesc(C.Structure):
     _fields_ = [("plane", vp * 16), ("nstride", i64 * 16), ("cval", f32 * 16), ("C", i32)]
 
 
+class FusionLayer(C.Structure):
+    """mivos_fusion_layer"""
+    _fields_ = [("w16", vp), ("scale16", vp), ("bias", vp)]
+
+
+class FusionNetDesc(C.Structure):
+    """mivos_fusion_net_desc"""
+    _fields_ = [("layer", FusionLayer * 6), ("final_bias", vp), ("x16", vp), ("logits", vp), ("scratch", vp),
+                ("scratch_floats", i64), ("batch", i32), ("height", i32), ("width", i32), ("workspace", vp),
+                ("workspace_bytes", i64)]
+
+
 # name -> (restype, argtypes); every symbol include/mivos_hip.h declares
 PROTOTYPES = {
     "mivos_version": (C.c_int, []),
     "mivos_last_error": (C.c_char_p, []),
     "mivos_device_check": (C.c_int, [C.c_int]),
     "mivos_conv2d_fused": (C.c_int, [C.POINTER(ConvDesc), vp]),
+    "mivos_fusion_net_scratch_floats": (i64, [C.c_int, C.c_int, C.c_int]),
+    "mivos_fusion_net_forward": (C.c_int, [C.POINTER(FusionNetDesc), vp]),
     "mivos_pack_weights_f16x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "mivos_pack_activation_sh32": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_unpack_activation_sh32": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -57,6 +57,8 @@ class FusionNet(nn.Module):
     def run(self, x):
         """x NHWC [B,H,W,16] (9 real channels: im, seg1, seg2, attn(2), time(2)) -> logits [B,H,W,1]."""
         c1, c2a, c2b, c3a, c3b, fin = self.plan()
+        if ops.CONV_PRECISION == "f16x3" and ops.PROFILE is None:
+            return ops.fusion_net_forward(x, (c1, c2a, c2b, c3a, c3b), fin)     # the same launches behind one C-ABI call
         x = ops.conv(x, c1, relu_out=True)
         r = ops.conv(x, c2a, relu_out=True)
         x = ops.conv(r, c2b, res=x, relu_out=True)        # relu(x + conv2(x))   fusion_net.py:42-43

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, InterleaveDesc, MivosHipError, check
+from ._lib import ConvDesc, FusionNetDesc, InterleaveDesc, MivosHipError, check
 
 _checked_devices = set()
 # "f16x3": error-compensated fp16 MFMA convolutions (3 products per term, fp32-class accuracy, 5.3x the
@@ -351,6 +351,31 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
             var = lib.mivos_conv2d_variant(m, L.cout)
         PROFILE.append((var, 2.0 * m * L.cout * L.k * L.k * cin, ev0, ev1, (m, cin, L.cout, L.k, L.stride, res is not None)))
     return (out, out2) if dual else out
+
+
+def fusion_net_forward(x16, layers, final):
+    """FusionNet.forward as one C-ABI call (mivos_fusion_net_forward): x16 [B,H,W,16] fp32, layers = the five packed 3x3
+    ConvLayers (conv1[0], conv2[0], conv2[2], conv3[0], conv3[2]), final = final_conv's ConvLayer -> logits [B,H,W,1].
+    The f16x3 back-end only (the per-layer path of FusionNet.run serves "f32" and the profiler)."""
+    _ensure_device(x16)
+    b, h, w, c = x16.shape
+    assert c == 16 and x16.is_contiguous() and CONV_PRECISION == "f16x3"
+    lib = _lib.load()
+    d = FusionNetDesc()
+    for i, L in enumerate(list(layers) + [final.projection()]):
+        w16, scale16 = L.f16x3()
+        d.layer[i].w16, d.layer[i].scale16 = w16.data_ptr(), scale16.data_ptr()
+        d.layer[i].bias = L.bias.data_ptr() if L.bias is not None else None
+    d.final_bias = final.bias.data_ptr() if final.bias is not None else None
+    out = torch.empty((b, h, w, 1), dtype=torch.float32, device=x16.device)
+    n = lib.mivos_fusion_net_scratch_floats(b, h, w)
+    scratch = _workspace(4 * n, x16.device, "fusion_net")
+    ws = _workspace(SPLITK_WORKSPACE_BYTES, x16.device)
+    d.x16, d.logits, d.scratch, d.scratch_floats = _f32(x16).data_ptr(), out.data_ptr(), scratch.data_ptr(), n
+    d.batch, d.height, d.width = b, h, w
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    check(lib.mivos_fusion_net_forward(C.byref(d), _stream()))
+    return out
 
 
 def maxpool3x3s2(x, act_tag=None, as_act=False):

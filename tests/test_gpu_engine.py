@@ -147,6 +147,26 @@ def test_segment_with_query_public_api_vs_oracle(nets, synthetic_states):
     assert float((out.cpu() - O.aggregate_wbg(torch.sigmoid(ref_logit), keep_bg=True)).abs().max()) < 2.5e-4
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 48, 80), (5, 480, 864), (2, 37, 61)])
+def test_fusion_net_forward_entry_equals_the_layer_by_layer_path(nets, B, H, W):
+    """mivos_fusion_net_forward (one C-ABI call per FusionNet forward) issues the launches of FusionNet.run's
+    layer-by-layer path: bit-identical logits, on the benchmark's batch (5 objects at 480x864) and on ragged sizes."""
+    from mivos_amd import ops
+    _, fuse = nets
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.zeros(B, H, W, 16)
+    x[..., :9] = torch.randn(B, H, W, 9, generator=g)
+    x = x.to(DEV)
+    one_call = fuse.run(x)
+    old, ops.PROFILE = ops.PROFILE, []                 # the profiler's path: every convolution its own call
+    try:
+        layered = fuse.run(x)
+    finally:
+        ops.PROFILE = old
+    assert one_call.shape == layered.shape == (B, H, W, 1)
+    assert torch.equal(one_call, layered) and bool(torch.isfinite(one_call).all())
+
+
 def test_fusion_generator_call_pattern_vs_oracle(nets, synthetic_states):
     """generation/fusion_generator.py:43-78: the second caller of the network API grows its bank with
     torch.cat on the logical [K,C,T,h,w] tensors and keeps a temporary last-frame entry.  Teacher-forced:
