@@ -10,6 +10,11 @@ from .._lib import MivosHipError
 from .propagation.modules import ConvParams
 
 
+import os
+
+ONE_CALL = os.environ.get("MIVOS_FUSION_ONE_CALL", "1") != "0"     # tuning / A-B only: 0 = issue the six launches from Python
+
+
 class FusionNet(nn.Module):
     def __init__(self):
         super().__init__()
@@ -57,7 +62,7 @@ class FusionNet(nn.Module):
     def run(self, x):
         """x NHWC [B,H,W,16] (9 real channels: im, seg1, seg2, attn(2), time(2)) -> logits [B,H,W,1]."""
         c1, c2a, c2b, c3a, c3b, fin = self.plan()
-        if ops.CONV_PRECISION == "f16x3" and ops.PROFILE is None:
+        if ops.CONV_PRECISION == "f16x3" and ops.PROFILE is None and ONE_CALL:
             return ops.fusion_net_forward(x, (c1, c2a, c2b, c3a, c3b), fin)     # the same launches behind one C-ABI call
         x = ops.conv(x, c1, relu_out=True)
         r = ops.conv(x, c2a, relu_out=True)
