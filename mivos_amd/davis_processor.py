@@ -19,6 +19,7 @@ class DAVISProcessor:
     def __init__(self, prop_net, fuse_net, s2m_net, images, num_objects, device="cuda:0"):
         self.device = torch.device(device)
         self.s2m_net = s2m_net.to(self.device)
+        self.s2m_net.refresh_plan_if_stale()                    # packed weights follow parameters changed since the last clip
         _, self.pad = pad_divide_by(images[:, :1], 16, images.shape[-2:])
         self.t = images.shape[1]
         self.h, self.w = images.shape[-2:]                      # true dimensions (the reference overwrites them with the padded

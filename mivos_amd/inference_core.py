@@ -84,8 +84,9 @@ class InferenceCore:
             raise ops.MivosHipError("InferenceCore needs an MI355X device; mivos_amd has no CPU execution path")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        # .to() of a network that already lives on the device keeps its compiled plan (packed weights); parameters
-        # mutated in place since the plan was built are detected once per clip
+        # .to() of a network that already lives on the device keeps its compiled plan (packed weights); parameters that
+        # autograd saw change since the plan was built (optimiser steps, p.copy_, re-assignment) are detected here, once per
+        # clip; writes through p.data are invisible to that check and need invalidate_plan() (model/plan_cache.py)
         self.prop_net = prop_net.to(self.device)
         self.prop_net.refresh_plan_if_stale()
         if fuse_net is not None:
@@ -188,19 +189,22 @@ class InferenceCore:
         keys[:, :nc], values[:, :nc] = self._certain_k, self._certain_v
         # the affinity kernel streams keys pre-split into fp16 hi/lo pairs (ops.split_keys): a second bank of the same size,
         # every slot converted once when it is written
-        ksplit = torch.empty_like(keys)
-        ops.split_keys(keys[:, :nc], ksplit[:, :nc])
+        # (f16x3 only: the exact-fp32 verification mode streams the fp32 rows themselves)
+        ksplit = torch.empty_like(keys) if ops.CONV_PRECISION == "f16x3" else None
+        if ksplit is not None:
+            ops.split_keys(keys[:, :nc], ksplit[:, :nc])
         hw = kh * kw
         for si, st in enumerate(steps):
             q = self._query(st.ti, upcoming=[s2.ti for s2 in steps[si + 1:si + self.QUERY_BATCH]])
             prob_k = self.prop_net.segment(keys[:, :st.n_read].reshape(K, st.n_read * hw, CK),
                                            values[:, :st.n_read].reshape(K, st.n_read * hw, CV), q,
-                                           keys_split=ksplit[:, :st.n_read].reshape(K, st.n_read * hw, CK))
+                                           keys_split=None if ksplit is None else ksplit[:, :st.n_read].reshape(K, st.n_read * hw, CK))
             out = ops.aggregate(prob_k.unsqueeze(1), keep_bg=True)            # [K+1,1,nh,nw]
             if st.slot is not None:
                 self.prop_net.memorize_into(self.get_image_buffered(st.ti), out[1:],
                                             key_out=keys[:, st.slot], val_out=values[:, st.slot])
-                ops.split_keys(keys[:, st.slot], ksplit[:, st.slot])
+                if ksplit is not None:
+                    ops.split_keys(keys[:, st.slot], ksplit[:, st.slot])
             if st.fuse:
                 out = self.fuse_one_frame(closest, idx, st.ti, self.prob[:, st.ti], out, key_k, q.k16)
             self.prob[:, st.ti] = out.to(self.result_dev)

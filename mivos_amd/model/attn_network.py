@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import MivosHipError
+from .plan_cache import PlanCache
 from .propagation.modules import KeyValue, MaskRGBEncoder, RGBEncoder, run_trunk
 
 
@@ -24,7 +25,7 @@ class AttentionMemory(nn.Module):
             return ops.attention_weights(keys, q)
 
 
-class AttentionReadNetwork(nn.Module):
+class AttentionReadNetwork(PlanCache):
     def __init__(self):
         super().__init__()
         self.mask_rgb_encoder = MaskRGBEncoder()
@@ -34,20 +35,6 @@ class AttentionReadNetwork(nn.Module):
         self.memory = AttentionMemory()
         for p in self.parameters():
             p.requires_grad = False
-        self._plan = None
-
-    def _apply(self, fn, *a, **k):
-        p = self.kv_q_f16.key_proj.weight
-        before = (p.device, p.dtype, p.data_ptr())
-        out = super()._apply(fn, *a, **k)
-        p = self.kv_q_f16.key_proj.weight
-        if (p.device, p.dtype, p.data_ptr()) != before:
-            self._plan = None
-        return out
-
-    def load_state_dict(self, *a, **k):
-        self._plan = None
-        return super().load_state_dict(*a, **k)
 
     def plan(self):
         if self._plan is None:
@@ -56,6 +43,7 @@ class AttentionReadNetwork(nn.Module):
             with torch.no_grad():
                 self._plan = dict(menc=self.mask_rgb_encoder.compile(), qenc=self.rgb_encoder.compile(),
                                   kv_m=self.kv_m_f16.compile(), kv_q=self.kv_q_f16.compile())
+                self._stamp_plan()
         return self._plan
 
     def _mem_keys(self, image, mask, other):

@@ -7,6 +7,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import MivosHipError
+from .plan_cache import PlanCache
 from .propagation.modules import ConvParams
 
 
@@ -15,7 +16,7 @@ import os
 ONE_CALL = os.environ.get("MIVOS_FUSION_ONE_CALL", "1") != "0"     # tuning / A-B only: 0 = issue the six launches from Python
 
 
-class FusionNet(nn.Module):
+class FusionNet(PlanCache):
     def __init__(self):
         super().__init__()
         self.conv1 = nn.Sequential(ConvParams(9, 32, 3, padding=1), nn.ReLU())
@@ -23,31 +24,6 @@ class FusionNet(nn.Module):
         self.conv3 = nn.Sequential(ConvParams(32, 32, 3, padding=1), nn.ReLU(), ConvParams(32, 32, 3, padding=1))
         self.relu = nn.ReLU()
         self.final_conv = ConvParams(32, 1, 3, padding=1)
-        self._plan = None
-
-    def _apply(self, fn, *a, **k):
-        p = self.final_conv.weight
-        before = (p.device, p.dtype, p.data_ptr())
-        out = super()._apply(fn, *a, **k)
-        p = self.final_conv.weight
-        if (p.device, p.dtype, p.data_ptr()) != before:       # a no-op .to(device) keeps the packed weights
-            self._plan = None
-        return out
-
-    def invalidate_plan(self):
-        """Call after mutating parameters in place; load_state_dict / device moves do it themselves."""
-        self._plan = None
-
-    def _param_versions(self):
-        return sum(p._version for p in self.parameters())
-
-    def refresh_plan_if_stale(self):
-        if self._plan is not None and self._plan_versions != self._param_versions():
-            self._plan = None
-
-    def load_state_dict(self, *a, **k):
-        self._plan = None
-        return super().load_state_dict(*a, **k)
 
     def plan(self):
         if self._plan is None:
@@ -56,7 +32,7 @@ class FusionNet(nn.Module):
             with torch.no_grad():
                 self._plan = (self.conv1[0].pack(cin_pad=16), self.conv2[0].pack(), self.conv2[2].pack(),
                               self.conv3[0].pack(), self.conv3[2].pack(), self.final_conv.pack())
-                self._plan_versions = self._param_versions()
+                self._stamp_plan()
         return self._plan
 
     def run(self, x):

@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from ... import ops
 from ..._lib import MivosHipError
+from ..plan_cache import PlanCache
 from .modules import (ConvParams, KeyValue, MaskRGBEncoder, ResBlock, RGBEncoder, UpsampleBlock,
                       run_resblock, run_resblock_acts, run_skip_branch, run_trunk, run_up_branch)
 
@@ -106,7 +107,7 @@ MAX_TOP_K = 64      # csrc/memory_read.hip: candidate lists are sized for k <= 6
                     # DAVIS single-object configuration uses 20)
 
 
-class PropagationNetwork(nn.Module):
+class PropagationNetwork(PlanCache):
     def __init__(self, top_k=50):
         super().__init__()
         if top_k is None or not (1 <= int(top_k) <= MAX_TOP_K):
@@ -119,38 +120,8 @@ class PropagationNetwork(nn.Module):
         self.memory = EvalMemoryReader(top_k, km=None)
         self.attn_memory = AttentionMemory(top_k)
         self.decoder = Decoder()
-        self._plan = None
 
-    # ---- compiled-plan management -------------------------------------------------------
-    def _apply(self, fn, *a, **k):
-        # .to()/.cuda() of an already placed network keeps every parameter's storage: keep the compiled plan then
-        # (InferenceCore re-applies .to(device) for every clip; re-packing ~120 layers each time would be wasted work)
-        before = self._storage_key()
-        out = super()._apply(fn, *a, **k)
-        if self._storage_key() != before:
-            self._plan = None
-        return out
-
-    def _storage_key(self):
-        p = self.kv_q_f16.key_proj.weight
-        return (p.device, p.dtype, p.data_ptr())
-
-    def _param_versions(self):
-        return sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
-
-    def load_state_dict(self, *a, **k):
-        self._plan = None
-        return super().load_state_dict(*a, **k)
-
-    def invalidate_plan(self):
-        """Call after mutating parameters in place (``p.data.copy_``, optimiser steps) so that the packed weights are
-        rebuilt; ``load_state_dict`` / device moves do it themselves, and InferenceCore checks once per clip."""
-        self._plan = None
-
-    def refresh_plan_if_stale(self):
-        if self._plan is not None and self._plan["versions"] != self._param_versions():
-            self._plan = None
-
+    # ---- compiled plan (packed weights; bookkeeping in model/plan_cache.py) -------------------
     def plan(self):
         if self._plan is None:
             dev = self.kv_q_f16.key_proj.weight.device
@@ -160,7 +131,8 @@ class PropagationNetwork(nn.Module):
             with torch.no_grad():
                 self._plan = dict(menc=self.mask_rgb_encoder.compile(), qenc=self.rgb_encoder.compile(),
                                   kv_m=self.kv_m_f16.compile(), kv_q=self.kv_q_f16.compile(),
-                                  dec=self.decoder.compile(), versions=self._param_versions())
+                                  dec=self.decoder.compile())
+                self._stamp_plan()
         return self._plan
 
     # ---- internal fast path (NHWC) ------------------------------------------------------

@@ -12,13 +12,12 @@ object per interaction).  Execution plan:
   * head: low-level projection and the x4 upsampled ASPP output land in channel slices of one 320-channel buffer
     (48 + 16 zero + 256; the classifier's weights are re-indexed accordingly), 3x3 classifier on the LDS-DMA kernels.
 """
-import copy
-
 import torch
 import torch.nn as nn
 
 from ... import ops
 from ..._lib import MivosHipError
+from ..plan_cache import PlanCache
 from ..propagation.modules import BatchNormParams, Bottleneck, ConvParams, run_bottleneck
 
 
@@ -65,27 +64,13 @@ class _HeadV3Plus(nn.Module):
                                         ConvParams(256, num_classes, 1))
 
 
-class S2M(nn.Module):
+class S2M(PlanCache):
     def __init__(self, num_classes=1):
         super().__init__()
         if num_classes != 1:
             raise MivosHipError("S2M: the scribble-to-mask network has one output class")
         self.backbone = _Backbone()
         self.classifier = _HeadV3Plus(2048, 256, num_classes, (6, 12, 18))
-        self._plan = None
-
-    def _apply(self, fn, *a, **k):
-        p = self.backbone.conv1.weight
-        before = (p.device, p.dtype, p.data_ptr())
-        out = super()._apply(fn, *a, **k)
-        p = self.backbone.conv1.weight
-        if (p.device, p.dtype, p.data_ptr()) != before:
-            self._plan = None
-        return out
-
-    def load_state_dict(self, *a, **k):
-        self._plan = None
-        return super().load_state_dict(*a, **k)
 
     def plan(self):
         if self._plan is None:
@@ -110,6 +95,7 @@ class S2M(nn.Module):
                 cls0 = ops.ConvLayer(w, cl.scale, cl.bias, 1, 1)
                 self._plan = dict(stem=b.conv1.pack(b.bn1, cin_pad=8), stages=stages, aspp=aspp, pool=pool, proj_main=proj_main,
                                   proj_pool=proj_pool, low=low, cls0=cls0, cls1=c.classifier[3].pack())
+                self._stamp_plan()
         return self._plan
 
     def forward(self, x):
@@ -144,9 +130,8 @@ class S2M(nn.Module):
         for i, L in enumerate(p["aspp"]):
             ops.conv(y, L, relu_out=True, out=cat[..., 256 * i:256 * (i + 1)])
         pooled = ops.conv(ops.global_avgpool(y), p["pool"], relu_out=True)             # [1,1,1,256], constant over the image
-        proj = copy.copy(p["proj_main"])
-        proj.bias = ops.conv(pooled, p["proj_pool"]).view(256)                          # scale * (W_pool . pooled) + BN shift
-        aspp_out = ops.conv(cat, proj, relu_out=True)                                   # Dropout(0.1) is the identity in eval
+        pool_bias = ops.conv(pooled, p["proj_pool"]).view(256)                          # scale * (W_pool . pooled) + BN shift
+        aspp_out = ops.conv(cat, p["proj_main"], relu_out=True, bias=pool_bias)         # Dropout(0.1) is the identity in eval
         cat2 = torch.zeros((1, H // 4, W // 4, 320), dtype=torch.float32, device=x.device)
         ops.conv(low_level, p["low"], relu_out=True, out=cat2[..., :64])
         ops.resize_bilinear_nhwc(aspp_out, H // 4, W // 4, out=cat2[..., 64:])

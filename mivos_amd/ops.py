@@ -91,7 +91,7 @@ class ConvLayer:
         """A 3x3 / pad 1 layer with ONE output channel as a 1x1 layer with 16 outputs, row k = the weights of tap k
         (9 real rows): the GEMM kernels then read the input once and `tap_sum9` adds the nine shifted products."""
         if self.proj is None:
-            assert self.cout == 1 and self.k == 3 and self.scale is None
+            assert self.cout == 1 and self.k == 3 and self.scale is None and self.dil == 1
             w = self.w.new_zeros((16, 1, 1, self.cin))
             w[:9, 0, 0] = self.w[0].reshape(9, self.cin)
             self.proj = ConvLayer(w, None, None, 1, 0)
@@ -100,8 +100,8 @@ class ConvLayer:
     def slice_cin(self, c0, c1, keep_bias):
         """The same layer restricted to input channels [c0, c1) (a convolution over concatenated inputs is the sum of the
         convolutions over the parts; the bias / BN shift goes with one part)."""
-        assert self.scale is None
-        return ConvLayer(self.w[..., c0:c1].contiguous(), None, self.bias if keep_bias else None, self.stride, self.pad)
+        assert self.scale is None and self.split == self.cout
+        return ConvLayer(self.w[..., c0:c1].contiguous(), None, self.bias if keep_bias else None, self.stride, self.pad, dil=self.dil)
 
     def _f16x3_scale(self):
         """(2^s, scale * 2^-s): the exact power-of-two pre-scaling of the fp16 hi/lo weight split."""
@@ -259,10 +259,11 @@ def to_f32(a):
     return y
 
 
-def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out_act=False, tag=None):
+def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out_act=False, tag=None, bias=None):
     """y = act(conv(act_in(x)) * scale + bias + res).  x: fp32 [N,H,W,Cin] view or an Act (then the LDS-DMA kernels run);
     res: fp32 view or Act; out_act=True returns an Act (only from Act inputs; `out` may be a preallocated Act, `tag` selects
-    a scratch buffer).  Returns out (and out2 when the layer is split, i.e. (out, out2))."""
+    a scratch buffer); bias: per-call replacement of the layer's bias vector ([Cout] fp32 on the device; the packed weights
+    and their caches stay the layer's).  Returns out (and out2 when the layer is split, i.e. (out, out2))."""
     if isinstance(x, Act) and L.dil > 1:
         x = to_f32(x)                       # atrous convolutions run on the register-staged kernels (fp32 input, bounds masks)
     from_act = isinstance(x, Act)
@@ -276,7 +277,7 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
         raise MivosHipError("conv: an Act input needs the f16x3 back-end, Cout > 1 and relu applied by its producer")
     if out_act and not from_act:
         raise MivosHipError("conv: SH32 outputs are written by the LDS-DMA kernels only (Act input)")
-    if (L.cout == 1 and L.k == 3 and L.stride == 1 and L.pad == 1 and L.scale is None and CONV_PRECISION == "f16x3"
+    if (L.cout == 1 and L.k == 3 and L.stride == 1 and L.pad == 1 and L.dil == 1 and L.scale is None and CONV_PRECISION == "f16x3"
             and not from_act and res is None and not relu_out and cin % 32 == 0):
         # one output channel: 1x1 projection to the nine tap products (reads x once) + 9-point sum, instead of a dot-product
         # kernel that re-reads every pixel for each of its nine neighbours
@@ -307,7 +308,11 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
         d.x, d.w, d.precision = _f32(x).data_ptr(), L.w.data_ptr(), 0
         d.scale = L.scale.data_ptr() if L.scale is not None else None
         d.x_nstride, d.x_pstride = _nhwc_strides(x)
-    d.bias = L.bias.data_ptr() if L.bias is not None else None
+    if bias is not None:
+        assert bias.shape == (L.cout,) and bias.dtype == torch.float32 and bias.is_contiguous() and bias.device == dev
+        d.bias = bias.data_ptr()
+    else:
+        d.bias = L.bias.data_ptr() if L.bias is not None else None
     d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = n, h, w, cin, L.cout, L.k, L.k
     d.stride, d.pad, d.Ho, d.Wo, d.split, d.dilation = L.stride, L.pad, ho, wo, L.split, L.dil
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)

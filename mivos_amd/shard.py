@@ -22,8 +22,16 @@ def init_distributed(backend=None):
         if backend is None:
             # MIVOS_DIST_BACKEND=gloo: plumbing tests of the multi-rank path on a box with fewer GPUs than ranks
             backend = os.environ.get("MIVOS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
-            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+        if torch.cuda.is_available():
+            n_dev = torch.cuda.device_count()
+            if backend == "nccl":
+                # RCCL needs one device per rank: two ranks on one GPU end in a duplicate-device error or a hang
+                if local >= n_dev:
+                    raise RuntimeError(f"LOCAL_RANK {local} but only {n_dev} GPU(s) visible: the nccl (RCCL) backend needs one GPU per "
+                                       f"rank (MIVOS_DIST_BACKEND=gloo runs the multi-rank plumbing on fewer GPUs)")
+                torch.cuda.set_device(local)
+            else:
+                torch.cuda.set_device(local % n_dev)         # gloo plumbing runs: ranks may share a GPU
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

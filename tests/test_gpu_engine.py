@@ -44,6 +44,39 @@ def mean_iou(a, b, k):
     return float(np.mean([compute_np_iou(a == j, b == j) for j in range(1, k + 1)]))
 
 
+ARBITRATION_FACTOR, ARBITRATION_FLOOR = 2.0, 2.5e-4
+
+
+def fp64_gate(tag, eng_prob, ref32_prob, ref64_prob):
+    """The closed-loop parity gate: per frame, the engine's probabilities may be at most
+    ARBITRATION_FACTOR times as far from an fp64 run of the reference algorithm as the reference's OWN fp32 arithmetic is,
+    plus the probability equivalent (2.5e-4) of the north star's 1e-3 logit bar.  The algorithm is discontinuous (top-k
+    membership, argmax) and feeds its masks back, so two fp32 implementations legitimately drift apart by more than 1e-3 on
+    the pixels behind a neighbour whose rank-k / k+1 margin is inside fp32 rounding; the fp64 run says which side drifted.
+    Prints the numbers, appends them to gpurun_out/parity_ratios.jsonl (a record per run) and returns (passed, record)."""
+    e = (eng_prob.cpu().double() - ref64_prob).abs()
+    r = (ref32_prob.cpu().double() - ref64_prob).abs()
+    ef, rf = e.amax(dim=(0, 2, 3, 4)), r.amax(dim=(0, 2, 3, 4))                      # per frame
+    live = rf > 0                                                                  # (interacted frames are exact on both sides)
+    ratio = float((ef[live] / rf[live]).max()) if bool(live.any()) else 0.0
+    margin = float((ARBITRATION_FACTOR * rf + ARBITRATION_FLOOR - ef).min())
+    rec = dict(test=tag, frames=int(ef.numel()), engine_vs_fp64_max=float(ef.max()), ref32_vs_fp64_max=float(rf.max()),
+               worst_frame_ratio=round(ratio, 3), gate_margin=margin,
+               frac_gt_1e3_engine=float((e > 1e-3).double().mean()), frac_gt_1e3_ref32=float((r > 1e-3).double().mean()),
+               per_frame_engine=[float(x) for x in ef], per_frame_ref32=[float(x) for x in rf])
+    print(f"{tag}: per-frame max|dprob| engine-fp64 {rec['engine_vs_fp64_max']:.2e} vs reference(fp32)-fp64 {rec['ref32_vs_fp64_max']:.2e}; "
+          f"worst per-frame ratio {ratio:.2f} (gate: e <= {ARBITRATION_FACTOR} r + {ARBITRATION_FLOOR}, margin {margin:.2e}); "
+          f"frac(|d| > 1e-3) engine {rec['frac_gt_1e3_engine']:.1e} reference {rec['frac_gt_1e3_ref32']:.1e}")
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_ratios.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    return bool((ef <= ARBITRATION_FACTOR * rf + ARBITRATION_FLOOR).all()), rec
+
+
 def test_query_encoder_and_memorize_golden(nets, ops_golden):
     prop, _ = nets
     g = ops_golden
@@ -207,7 +240,7 @@ def test_fusion_generator_call_pattern_vs_oracle(nets, synthetic_states):
                 prev = None
 
 
-def test_end_to_end_golden(nets, golden_dir):
+def test_end_to_end_golden(nets, golden_dir, synthetic_states):
     """Same 3-interaction session (incl. fusion) the unmodified reference ran to produce e2e_small.npz."""
     prop, fuse = nets
     with np.load(os.path.join(golden_dir, "e2e_small.npz")) as z:
@@ -215,15 +248,18 @@ def test_end_to_end_golden(nets, golden_dir):
     c = json.loads(str(g["config"]))
     images, gt = O.synthetic_clip(c["t"], c["h"], c["w"], c["k"], c["seed"])
     core = InferenceCore(prop, fuse, images, c["k"], mem_freq=c["mem_freq"], device=DEV)
+    o64 = O.OracleCore(synthetic_states[0], synthetic_states[1], images, c["k"], mem_freq=c["mem_freq"], top_k=c["top_k"], dtype=torch.float64)
     for n, idx in enumerate(c["interactions"]):
         out = core.interact(gt[idx], idx)
+        o64.interact(gt[idx], idx)
         ref = g[f"masks_{n}"]
         assert out.shape == ref.shape and out.dtype == np.uint8
         iou = mean_iou(out, ref, c["k"])
-        dprob = float((core.prob.cpu() - T(g[f"prob_{n}"])).abs().max())
-        print(f"interaction {n}: IoU {iou:.6f}  max|dprob| {dprob:.2e}  mismatching px {int((out != ref).sum())}")
+        print(f"interaction {n}: IoU {iou:.6f}  mismatching px {int((out != ref).sum())}")
         assert iou >= 0.999
-        assert dprob < 2e-3
+        # the golden probabilities are the unmodified reference's fp32 run; the fp64 run of the oracle arbitrates
+        ok, rec = fp64_gate(f"e2e_golden[{n}]", core.prob, T(g[f"prob_{n}"]), o64.prob)
+        assert ok, rec
     assert core.propagated_frames == 6 + 5 + 4
     # update_mask_only keeps its contract
     m = core.update_mask_only(core.prob[:, 2], 2)
@@ -271,11 +307,9 @@ def test_480p_propagation_vs_oracle(nets, synthetic_states, K):
     for idx in (0, 3):                                               # second one fuses frames 1, 2
         out, ref, _ = core.interact(gt[idx], idx), ocore.interact(gt[idx], idx), o64.interact(gt[idx], idx)
         iou = mean_iou(out, ref, K)
-        e = (core.prob.cpu().double() - o64.prob).abs().amax(dim=(0, 2, 3, 4))
-        r = (ocore.prob.double() - o64.prob).abs().amax(dim=(0, 2, 3, 4))
-        print(f"K={K} interact({idx}): IoU {iou:.6f} per-frame max|dprob| engine-fp64 {e.max():.2e} oracle32-fp64 {r.max():.2e}")
         assert iou >= 0.999
-        assert bool((e <= 2.0 * r + 2.5e-4).all()), (e.tolist(), r.tolist())
+        ok, rec = fp64_gate(f"480p_closed_loop[K={K},interact({idx})]", core.prob, ocore.prob, o64.prob)
+        assert ok, rec
 
 
 @pytest.mark.parametrize("K,top_k,frames", [(5, 50, 8), (2, 50, 5)])
@@ -298,12 +332,10 @@ def test_headline_config_parity_with_fp64_arbitration(synthetic_states, K, top_k
     for idx in (0, frames - 1):
         out, r32, r64 = core.interact(gt[idx], idx), o32.interact(gt[idx], idx), o64.interact(gt[idx], idx)
         iou = mean_iou(out, r32, K)
-        e = (core.prob.cpu().double() - o64.prob).abs().amax(dim=(0, 2, 3, 4))          # per frame
-        r = (o32.prob.double() - o64.prob).abs().amax(dim=(0, 2, 3, 4))
-        print(f"K={K} interact({idx}): IoU vs fp32 oracle {iou:.6f}, vs fp64 {mean_iou(out, r64, K):.6f}; per-frame max|dprob| "
-              f"engine-fp64 {e.max():.2e} oracle32-fp64 {r.max():.2e}; worst ratio {float((e / (r + 1e-12)).max()):.2f}")
+        print(f"K={K} interact({idx}): IoU vs fp32 oracle {iou:.6f}, vs fp64 {mean_iou(out, r64, K):.6f}")
         assert iou >= 0.999
-        assert bool((e <= 2.0 * r + 2.5e-4).all()), (e.tolist(), r.tolist())
+        ok, rec = fp64_gate(f"headline[K={K},interact({idx})]", core.prob, o32.prob, o64.prob)
+        assert ok, rec
     assert core.propagated_frames == o32.propagated == 2 * frames - 3
 
 
@@ -341,10 +373,12 @@ def test_interaction_order_and_reinteraction_vs_oracle(nets, synthetic_states):
     images, gt = O.synthetic_clip(5, 128, 160, 1, seed=43)
     core = InferenceCore(prop, fuse, images, 1, mem_freq=1, device=DEV)
     ocore = O.OracleCore(sd, fsd, images, 1, mem_freq=1, top_k=20)
-    for idx in (4, 0, 0):
-        out, ref = core.interact(gt[idx], idx), ocore.interact(gt[idx], idx)
+    o64 = O.OracleCore(sd, fsd, images, 1, mem_freq=1, top_k=20, dtype=torch.float64)
+    for n, idx in enumerate((4, 0, 0)):
+        out, ref, _ = core.interact(gt[idx], idx), ocore.interact(gt[idx], idx), o64.interact(gt[idx], idx)
         assert mean_iou(out, ref, 1) >= 0.999
-        assert float((core.prob.cpu() - ocore.prob).abs().max()) < 2.5e-3
+        ok, rec = fp64_gate(f"reinteraction[{n}:interact({idx})]", core.prob, ocore.prob, o64.prob)
+        assert ok, rec
     assert core.certain_mem_k.shape == (1, 128, 3, 8, 10) and core.certain_mem_v.shape == (1, 512, 3, 8, 10)
     assert core.propagated_frames == ocore.propagated
 
@@ -375,11 +409,10 @@ def test_topk_larger_than_memory_raises_like_reference(nets):
 
 def test_1080p_three_objects_with_fusion_vs_oracle(synthetic_states):
     """BASELINE config 5 geometry with its object count: 1080x1920, K = 3, top_k = 50, 3 frames, interact(0) then
-    interact(2): bank depth up to T = 2, the middle frame fused (3 propagated frames).  (The oracle materialises the affinity
-    like the reference, so T = 200 cannot be pinned on CPU: 160 GB; the long-bank behaviour is covered by the memory-read
-    tests at T = 23 / 40 and by bench.py --config 5.)  fp32 oracle only (an fp64 run costs ~40 s per 1080p frame on the
-    host): masks IoU >= 0.999, and the fed-back probabilities within the 1e-3 bar except on the few pixels where one of the two
-    fp32 runs flipped a decision (the K=5 test above carries the fp64 arbitration)."""
+    interact(2): bank depth up to T = 2, the middle frame fused (3 propagated frames), closed loop.  Masks IoU >= 0.999 vs
+    the fp32 oracle; probabilities through the fp64-arbitrated gate (fp64_gate; one fp64 frame of the CPU oracle costs ~40 s
+    at this size).  The deep-bank regime of config 5 (400 k - 1.2 M memory positions per object, > 2^31-byte bank strides)
+    is pinned by tests/test_gpu_ops.py::test_memory_read_deep_bank_1080p_vs_chunked_oracle."""
     sd, fsd = synthetic_states
     K = 3
     prop, fuse = PropagationNetwork(top_k=50), FusionNet()
@@ -388,13 +421,14 @@ def test_1080p_three_objects_with_fusion_vs_oracle(synthetic_states):
     images, gt = O.synthetic_clip(3, 1080, 1920, K, seed=71)
     core = InferenceCore(prop.eval(), fuse.eval(), images, K, mem_freq=1, device=DEV)
     o32 = O.OracleCore(sd, fsd, images, K, mem_freq=1, top_k=50)
+    o64 = O.OracleCore(sd, fsd, images, K, mem_freq=1, top_k=50, dtype=torch.float64)
     for idx in (0, 2):
-        out, r32 = core.interact(gt[idx], idx), o32.interact(gt[idx], idx)
+        out, r32, _ = core.interact(gt[idx], idx), o32.interact(gt[idx], idx), o64.interact(gt[idx], idx)
         iou = mean_iou(out, r32, K)
-        d = (core.prob.cpu() - o32.prob).abs()
-        print(f"1080p K=3 interact({idx}): IoU vs fp32 oracle {iou:.6f}; max|dprob| {float(d.max()):.2e}, frac(|dprob| > 1e-3) {float((d > 1e-3).float().mean()):.2e}")
+        print(f"1080p K=3 interact({idx}): IoU vs fp32 oracle {iou:.6f}")
         assert iou >= 0.999
-        assert float((d > 1e-3).float().mean()) < 2e-5
+        ok, rec = fp64_gate(f"1080p_K3_closed_loop[interact({idx})]", core.prob, o32.prob, o64.prob)
+        assert ok, rec
     assert core.propagated_frames == 3 and core.prob.shape == (4, 3, 1, 1088, 1920)
 
 

@@ -1,5 +1,6 @@
 """Parity of every HIP kernel family with the CPU oracle / plain torch fp32 (needs an MI355X).
 All calls go through the C ABI (mivos_amd.ops -> libmivos_hip.so)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -381,6 +382,65 @@ def test_memory_read_vs_oracle(T, h, w, K, top_k, mem_precision):
         assert bool(same[clear].all())
         assert torch.equal(idx[o][:, 0].long()[clear], ridx[0][clear])          # best first
         assert float((wgt[o].sum(1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("frames,scale", [(50, 1.0), (150, 1.7)])
+def test_memory_read_deep_bank_1080p_vs_chunked_oracle(frames, scale):
+    """BASELINE config 5's regime (1080x1920 -> 68x120 = 8160 positions per frame, K = 3, top-50, banks of 8160 x {50, 150}
+    = 408 k / 1.22 M positions per object) with the DEFAULT kernel selection (memread_select32_kernel from 400 k positions)
+    and InferenceCore's bank geometry: `bank[:, :n]` views of pre-allocated [K, slots, h, w, C] banks whose object strides
+    exceed 2^31 BYTES for keys, split keys and values.  Checker: oracle/chunked_read.py (the reference's affinity -> topk ->
+    softmax -> readout, 256 queries at a time, in fp64 and in fp32, as plain torch on this GPU - the materialised affinity
+    would be 40 - 120 GB).  Exact index sets on every query whose rank-50/51 margin (fp64) is clear, readout < 2e-4."""
+    from mivos_amd import _lib
+    from oracle import chunked_read as CR
+    K, h, w, top_k = 3, 68, 120, 50
+    hw = h * w
+    g = torch.Generator(device=DEV).manual_seed(7000 + frames)
+    kbank = torch.empty((K, 530, h, w, 128), dtype=torch.float32, device=DEV)     # object stride 2.21 GB
+    vbank = torch.empty((K, 264, h, w, 512), dtype=torch.float32, device=DEV)     # object stride 4.41 GB
+    sbank = torch.empty_like(kbank)
+    assert kbank.stride(0) * 4 > 2 ** 31 and vbank.stride(0) * 4 > 2 ** 32
+    for o in range(K):                                                             # (per object: bounded temporaries)
+        kbank[o, :frames] = torch.randn((frames, h, w, 128), generator=g, device=DEV) * scale
+        vbank[o, :frames] = torch.randn((frames, h, w, 512), generator=g, device=DEV)
+    q = torch.randn((hw, 128), generator=g, device=DEV) * scale
+    keys, vals = kbank[:, :frames].reshape(K, frames * hw, 128), vbank[:, :frames].reshape(K, frames * hw, 512)
+    assert keys.data_ptr() == kbank.data_ptr() and vals.data_ptr() == vbank.data_ptr()          # views, not copies
+    plan = (C.c_int32 * 8)()
+    assert _lib.load().mivos_memory_read_plan(K, frames * hw, hw, top_k, 1, plan) == 0
+    assert plan[6] == 128                                                         # the 128-query long-memory kernel is what runs
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f16x3"
+    try:
+        for t in range(0, frames, 25):                                            # the bank is split slot by slot, like do_pass
+            ops.split_keys(kbank[:, t:t + 25], sbank[:, t:t + 25])
+        ks = sbank[:, :frames].reshape(K, frames * hw, 128)
+        got = ops.memory_read(keys, vals, q, top_k, keys_split=ks)
+        idx, wgt = ops.memory_read_indices(keys, q, top_k, keys_split=ks)
+        ops.CONV_PRECISION = "f32"
+        got32 = ops.memory_read(keys, vals, q, top_k)                              # exact fp32 MFMA kernel, same geometry
+        idx32, _ = ops.memory_read_indices(keys, q, top_k)
+    finally:
+        ops.CONV_PRECISION = old
+    r64 = CR.memory_read_rows(keys, vals, q, top_k, dtype=torch.float64)
+    r32 = CR.memory_read_rows(keys, vals, q, top_k, dtype=torch.float32)
+    clear = r64["margin"] > 1e-5                                                  # [K, n_q]
+    ref_sets = torch.sort(r64["idx"], dim=2)[0]
+    for name, o_got, o_idx in (("f16x3/select32", got, idx), ("f32", got32, idx32)):
+        d64 = (o_got.double() - r64["readout"]).abs().amax(2)
+        d32 = (o_got - r32["readout"]).abs().amax(2)
+        same = (torch.sort(o_idx.long(), dim=2)[0] == ref_sets).all(dim=2)
+        print(f"deep bank T={frames} [{name}]: n_mem {frames * hw}, unclear queries {int((~clear).sum())} of {clear.numel()}, "
+              f"readout max|d| vs fp64 {float(d64[clear].max()):.2e} / vs fp32 oracle {float(d32[clear].max()):.2e}, "
+              f"oracle fp32 vs fp64 {float((r32['readout'].double() - r64['readout']).abs().amax(2)[clear].max()):.2e}, "
+              f"index sets equal on {int(same[clear].sum())} of {int(clear.sum())} clear queries")
+        assert int((~clear).sum()) <= clear.numel() // 100
+        assert bool(same[clear].all())
+        assert torch.equal(o_idx[..., 0].long()[clear], r64["idx"][..., 0][clear])                 # best first
+        assert float(d64[clear].max()) < 2e-4 and float(d32[clear].max()) < 2e-4
+        assert float(d64.max()) < 0.5                                             # an unclear query swaps ONE neighbour of weight ~1/k
+    assert float((wgt.sum(2) - 1).abs().max()) < 1e-5
+    assert int(idx.min()) >= 0 and int(idx.max()) < frames * hw
 
 
 def test_memory_read_sharp_scores_and_ties(mem_precision):

@@ -266,3 +266,33 @@ def test_split_key_rows_layout_and_f16x3_affinity_error():
     err16 = float((sh32.affinity_f16x3(keys, qk) - exact).abs().max())
     err32 = float(((keys @ (qk / (128 ** 0.5)).t()).double() - exact).abs().max())
     assert err16 < 2e-5 and err16 < 4 * err32 + 1e-6, (err16, err32)
+
+
+def test_plan_cache_staleness_rules():
+    """model/plan_cache.py: what drops a network's packed weights (CPU-side bookkeeping only, no kernels)."""
+    import torch
+    from mivos_amd.model.fusion_net import FusionNet
+    from mivos_amd.model.s2m.s2m_network import S2M
+    for net in (FusionNet(), S2M()):
+        p = next(net.parameters())
+        net._plan = "packed"; net._stamp_plan()
+        net.refresh_plan_if_stale()
+        assert net._plan == "packed"                      # nothing changed
+        net.to("cpu")
+        assert net._plan == "packed"                      # a no-op move keeps every storage
+        with torch.no_grad():
+            p.mul_(1.5)                                   # what an optimiser step does: autograd's version counter moves
+        net.refresh_plan_if_stale()
+        assert net._plan is None
+        net._plan = "packed"; net._stamp_plan()
+        p.data.copy_(torch.zeros_like(p))                 # invisible by design (documented): needs invalidate_plan()
+        net.refresh_plan_if_stale()
+        assert net._plan == "packed"
+        net.invalidate_plan()
+        assert net._plan is None
+        net._plan = "packed"; net._stamp_plan()
+        net.load_state_dict(net.state_dict())
+        assert net._plan is None
+        net._plan = "packed"; net._stamp_plan()
+        net.double()                                      # dtype move: new storages
+        assert net._plan is None

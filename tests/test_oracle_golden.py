@@ -43,6 +43,29 @@ def test_memory_read(ops):
     assert float((out - T(ops["mr_out"])).abs().max()) <= TOL
 
 
+def test_chunked_memory_read_equals_the_materialised_oracle(ops):
+    """oracle/chunked_read.py (the checker of the deep-bank GPU tests, where the [THW x HW] affinity cannot be materialised)
+    against stm_oracle.memory_read == the unmodified reference: golden vector, top-k and full-softmax cases, ragged query
+    blocks, fp32 and fp64."""
+    from oracle import chunked_read as CR
+    mk, mv, qk = T(ops["mr_mk"]), T(ops["mr_mv"]), T(ops["mr_qk"])
+    assert float((CR.memory_read(mk, mv, qk, 20) - T(ops["mr_out"])).abs().max()) <= 5e-6
+    g = torch.Generator().manual_seed(5)
+    mk, mv, qk = torch.randn(2, 128, 3, 7, 9, generator=g) * 1.5, torch.randn(2, 512, 3, 7, 9, generator=g), torch.randn(1, 128, 7, 9, generator=g) * 1.5
+    for top_k in (5, 50, None):
+        for dt in (torch.float32, torch.float64):
+            ref = torch.cat([O.memory_read(mk[o:o + 1].to(dt), mv[o:o + 1].to(dt), qk.to(dt), top_k) for o in range(2)], 0)
+            got = CR.memory_read(mk, mv, qk, top_k, dtype=dt, qblock=16)          # 63 queries: blocks of 16 + a ragged one
+            assert got.dtype == dt and float((got - ref).abs().max()) <= (5e-6 if dt == torch.float32 else 1e-12), (top_k, dt)
+    # index sets / weights / margins of the row-layout entry point
+    keys, vals = mk.reshape(2, 128, -1).transpose(1, 2), mv.reshape(2, 512, -1).transpose(1, 2)
+    r = CR.memory_read_rows(keys, vals, qk.reshape(128, -1).t(), 50, dtype=torch.float64, qblock=16)
+    a = O.affinity(mk.double(), qk.double())                                       # [2, THW, HW]
+    v, i = torch.topk(a, 51, dim=1)
+    assert torch.equal(r["idx"], i[:, :50].transpose(1, 2)) and float((r["margin"] - (v[:, 49] - v[:, 50])).abs().max()) < 1e-12
+    assert float((r["weights"].sum(2) - 1).abs().max()) < 1e-12
+
+
 def test_memory_read_topk_larger_than_memory_raises(ops):
     # reference behaviour: torch.topk raises when THW < top_k (SURVEY.md §7 hard part 2)
     with pytest.raises(RuntimeError):
