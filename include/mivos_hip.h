@@ -159,15 +159,21 @@ int mivos_tap_sum9(const float *t, const float *bias, float *out, int N, int H, 
  * FusionNet.forward (model/fusion_net.py:32-50; called per object and frame from inference_core.py:202-217) as one call:
  * x16 [batch][H][W][16] = the channel concatenation of fusion_net.py:38 (im 3, seg1, seg2, attn 2, time 2, 7 zero channels;
  * mivos_interleave_planes builds it) -> logits [batch][H][W] (the caller applies the sigmoid, inference_core.py:214).
- * layer[0..4] = conv1[0], conv2[0], conv2[2], conv3[0], conv3[2] (3x3), layer[5] = the 1x1 projection of final_conv to its
- * nine tap products (16 output channels, rows 0..8 = the taps); every layer as the precision-1 operands of
- * mivos_conv2d_fused (w16 from mivos_pack_weights_f16x3, scale16 = 2^-s per output channel, bias or NULL).
- * A host-side composition of mivos_conv2d_fused / mivos_tap_sum9 launches on `stream` (bit-identical to issuing them one by
- * one); scratch: mivos_fusion_net_scratch_floats() floats of device memory; workspace: optional split-K scratch.
+ * layer[0..4] = conv1[0], conv2[0], conv2[2], conv3[0], conv3[2] (3x3) as the precision-1 operands of mivos_conv2d_fused
+ * (w16 from mivos_pack_weights_f16x3, scale16 = 2^-s per output channel, bias or NULL); final_w = final_conv.weight as
+ * fp32 OHWI [1][3][3][32], final_bias = its bias (one float) or NULL.
+ * Launches on `stream`: conv1 (the library's direct 3x3 kernel), mivos_fusion_resblock twice, mivos_fusion_head.
+ * scratch: mivos_fusion_net_scratch_floats() floats of device memory; workspace: unused split-K scratch of conv1 (may be NULL).
+ *
+ * mivos_fusion_resblock - one residual block of the network in ONE launch (fusion_net.py:42-43 / :45-46):
+ *     y = relu(x + conv_b(relu(conv_a(x))))      x, y: dense fp32 [batch][H][W][32], x != y
+ *   the intermediate never leaves LDS; arithmetic = the f16x3 convolutions of mivos_conv2d_fused (same products, same order).
+ * mivos_fusion_head - final_conv (3x3, pad 1, 32 -> 1; fusion_net.py:49) in exact fp32: x [batch][H][W][32] -> logits [batch][H*W].
  * -------------------------------------------------------------------------------------------- */
 typedef struct { const void *w16; const float *scale16; const float *bias; } mivos_fusion_layer;
 typedef struct {
-  mivos_fusion_layer layer[6];
+  mivos_fusion_layer layer[5];
+  const float *final_w;        /* final_conv.weight, fp32 OHWI [1][3][3][32] */
   const float *final_bias;     /* final_conv.bias (one float) or NULL */
   const float *x16;
   float *logits;
@@ -179,6 +185,10 @@ typedef struct {
 } mivos_fusion_net_desc;
 int64_t mivos_fusion_net_scratch_floats(int batch, int height, int width);
 int mivos_fusion_net_forward(const mivos_fusion_net_desc *d, void *stream);
+int mivos_fusion_resblock(const float *x, float *y, const mivos_fusion_layer *conv_a, const mivos_fusion_layer *conv_b, int batch,
+                          int height, int width, void *stream);
+int mivos_fusion_head(const float *x, const float *w_ohwi, const float *bias, float *logits, int batch, int height, int width,
+                      void *stream);
 
 /* --------------------------------------------------------------------------------------------
  * Space-time memory read: affinity (MFMA) -> streaming per-query top-k -> softmax over the k

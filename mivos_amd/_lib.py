@@ -38,7 +38,7 @@ class FusionLayer(C.Structure):
 
 class FusionNetDesc(C.Structure):
     """mivos_fusion_net_desc"""
-    _fields_ = [("layer", FusionLayer * 6), ("final_bias", vp), ("x16", vp), ("logits", vp), ("scratch", vp),
+    _fields_ = [("layer", FusionLayer * 5), ("final_w", vp), ("final_bias", vp), ("x16", vp), ("logits", vp), ("scratch", vp),
                 ("scratch_floats", i64), ("batch", i32), ("height", i32), ("width", i32), ("workspace", vp),
                 ("workspace_bytes", i64)]
 
@@ -51,6 +51,8 @@ PROTOTYPES = {
     "mivos_conv2d_fused": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "mivos_fusion_net_scratch_floats": (i64, [C.c_int, C.c_int, C.c_int]),
     "mivos_fusion_net_forward": (C.c_int, [C.POINTER(FusionNetDesc), vp]),
+    "mivos_fusion_resblock": (C.c_int, [vp, vp, C.POINTER(FusionLayer), C.POINTER(FusionLayer), C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_fusion_head": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_pack_weights_f16x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "mivos_pack_activation_sh32": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_unpack_activation_sh32": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

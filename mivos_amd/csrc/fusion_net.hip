@@ -1,16 +1,338 @@
-// FusionNet.forward (model/fusion_net.py:32-50) as ONE C-ABI call: a host-side composition of the library's own
-// launches - conv1 (16 -> 32, ReLU), two residual blocks (32 -> 32 twice each, ReLU after the add), the 32 -> 1 head as
-// its 1x1 projection to the nine tap products + mivos_tap_sum9 - in exactly the order, with exactly the kernels, that
-// mivos_amd/model/fusion_net.py::FusionNet.run issues them one by one (bit-identical results).  No new device code.
+// FusionNet.forward (model/fusion_net.py:32-50) for gfx950: three kinds of launches instead of the reference's six
+// convolutions + two adds, behind ONE C-ABI call (mivos_fusion_net_forward):
+//
+//   conv1 (9 -> 32, ReLU)                      the library's direct 3x3 kernel (conv_f16x3.hip: conv3x3_n32_direct_kernel<16>)
+//   2 x fusion_resblock_kernel                 x <- relu(x + conv_b(relu(conv_a(x))))   fusion_net.py:42-43 / :45-46, ONE launch each
+//   fusion_head_kernel                         final_conv 32 -> 1                       fusion_net.py:49
+//
+// Why: at 480p x 5 objects a 32-channel fp32 plane set is 265 MB, and the layer-by-layer path moved 3.6 GB per fused frame
+// (read x, read the residual, write y for each of four convolutions at ~3.5 TB/s = HBM bound, 190-240 us each) plus the head as a
+// 1x1 projection to nine tap planes (132 MB written, read again by a 9-point sum).  Fused, a residual block reads x once
+// (+ halo) and writes once, its intermediate r = relu(conv_a(x)) never leaves LDS, and the head reads x once and writes
+// one plane.
+//
+// fusion_resblock_kernel - persistent, 8 waves, one workgroup per CU (157 KB of LDS):
+//   * tile = 8 x 30 output pixels of one image; the intermediate is needed on 10 x 32 pixels (one 32-pixel MFMA column
+//     group per row - the reason for the 30), the input on 12 x 34;
+//   * the 12 x 34 x 32 input patch is split to fp16 hi / lo ONCE into LDS (80-byte pixel pitch: conflict-free fragment
+//     reads), the packed hi / lo weights of BOTH convolutions stay LDS-resident for the whole launch (92 KB);
+//   * phase A: waves take the 10 intermediate rows (waves 0, 1 two rows each, sharing the weight fragments): per tap and
+//     16-channel block three v_mfma_f32_32x32x16_f16 (lo*hi + hi*lo + hi*hi, fp32 accumulate - the arithmetic of every
+//     convolution of the engine, same product order as conv3x3_n32_direct_kernel); weights are the MFMA A operand, so a lane
+//     ends up with 4 consecutive channels of one pixel per register quad;
+//   * r = relu(acc * scale + bias), forced to ZERO outside the image (conv_b's zero padding), is split to hi / lo in
+//     registers and - after a barrier, every wave being done with the input patch - written OVER the patch;
+//   * phase B: 8 output rows, one per wave, the same MFMA sequence on r; epilogue: + bias + x (16-byte loads from
+//     global memory: the lines were just read for the patch and hit in L2), ReLU, 16-byte stores;
+//   * the next tile's patch is in flight in registers during the whole tile (requested a tile ahead, converted and
+//     written when phase B is done).
+// fusion_head_kernel - 3x3 / pad 1 / Cout = 1 on 32 channels in exact fp32 FMA (0.6 GFMA per launch: nothing for the
+//   vector ALU): a 10 x 34 patch in LDS, one output pixel per thread, weights through scalar loads.  HBM bound: reads x
+//   once, writes one plane.
 #include <string.h>
 
-#include "common.h"
+#include "conv_common.h"
+
+namespace mivos {
+
+typedef _Float16 fh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fh4 __attribute__((ext_vector_type(4)));
+
+constexpr int FB_TR = 8, FB_TC = 30;                 // output tile
+constexpr int FB_IR = FB_TR + 2, FB_IC = 32;         // intermediate region (rows, columns = one MFMA column group)
+constexpr int FB_PR = FB_TR + 4, FB_PC = FB_TC + 4;  // input patch
+constexpr int FB_PPX = 40;                           // halves per pixel of an LDS image (32 channels + 8 pad = 80 bytes)
+constexpr int FB_PW = 40;                            // halves per weight row
+constexpr int FB_IMG_P = FB_PR * FB_PC * FB_PPX;     // halves of one patch image (hi or lo)
+constexpr int FB_RPX = FB_IR * FB_IC + 2;            // intermediate pixels + 2 of slack (lanes 30, 31 of an output row read past it)
+constexpr int FB_IMG_R = FB_RPX * FB_PPX;
+constexpr int FB_WIMG = 9 * 32 * FB_PW;              // halves of one weight image (hi or lo of one convolution)
+constexpr int FB_LDS_HALVES = 2 * FB_IMG_P + 4 * FB_WIMG;
+constexpr int FB_NLD = (FB_PR * FB_PC * 8 + 511) / 512;   // float4 patch loads per thread
+static_assert(2 * FB_IMG_R <= 2 * FB_IMG_P, "the intermediate overlays the input patch");
+static_assert(FB_LDS_HALVES * 2 <= 160 * 1024, "LDS budget of one CU");
+
+struct FuseBlockP {
+  const float *x;                 // [B][H][W][32] fp32, dense
+  float *y;                       // same shape
+  const float *wa, *wb;           // mivos_pack_weights_f16x3 rows: [32][kpad4] float4 = hi0..3 | lo0..3 (fp16), K = tap * 32 + c
+  const float *sa, *sb;           // per-channel scale (2^-s of the weight pre-scaling)
+  const float *ba, *bb;           // per-channel bias or NULL
+  int B, H, W, kpad4, tiles_x, tiles_y, n_tiles;
+};
+
+// 3x3 taps x 32 channels on NR pixel rows at once (rows share the weight fragments).  X*: hi / lo images of the source
+// pixels with `pitch_px` pixels per row; row[r]: first source row of output row r; lane (i, h): pixel column i, k half h.
+template <int NR>
+__device__ __forceinline__ void fb_conv_rows(const _Float16 *Xh, const _Float16 *Xl, int pitch_px, const _Float16 *Wh, const _Float16 *Wl,
+                                             const int (&row)[NR], int i, int h, f32x16 (&acc)[NR]) {
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int boff = ((kh * 3 + kw) * 32 + i) * FB_PW + 8 * h;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const fh8 bh = *reinterpret_cast<const fh8 *>(Wh + boff + 16 * kb);
+        const fh8 bl = *reinterpret_cast<const fh8 *>(Wl + boff + 16 * kb);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int aoff = ((row[r] + kh) * pitch_px + i + kw) * FB_PPX + 8 * h + 16 * kb;
+          const fh8 ah = *reinterpret_cast<const fh8 *>(Xh + aoff);
+          const fh8 al = *reinterpret_cast<const fh8 *>(Xl + aoff);
+          // weights are the MFMA "A" operand: D[channel][pixel]; small terms first (the order of conv3x3_n32_direct_kernel)
+          acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[r], 0, 0, 0);
+          acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[r], 0, 0, 0);
+          acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[r], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void fusion_resblock_kernel(const FuseBlockP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
+  _Float16 *Ph = reinterpret_cast<_Float16 *>(fb_smem), *Pl = Ph + FB_IMG_P;   // input patch, hi | lo images
+  _Float16 *Rh = Ph, *Rl = Ph + FB_IMG_R;                                       // the intermediate overlays it
+  _Float16 *Wah = Ph + 2 * FB_IMG_P, *Wal = Wah + FB_WIMG, *Wbh = Wal + FB_WIMG, *Wbl = Wbh + FB_WIMG;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+
+  // ---- packed weights of both convolutions, once per (persistent) workgroup: [32][kpad4][hi0..3 | lo0..3] -> [tap][n][c]
+  for (int e = tid; e < 2 * 32 * 72; e += 512) {
+    const int conv = e / (32 * 72), ee = e - conv * (32 * 72);
+    const int n = ee / 72, q = ee - n * 72;
+    const f32x4 v = reinterpret_cast<const f32x4 *>(conv ? p.wb : p.wa)[(long long)n * p.kpad4 + q];
+    const int k = 4 * q, tap = k >> 5, c = k & 31;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 hh, ll;
+    hh.x = v.x; hh.y = v.y; ll.x = v.z; ll.y = v.w;
+    *reinterpret_cast<f32x2 *>((conv ? Wbh : Wah) + (tap * 32 + n) * FB_PW + c) = hh;
+    *reinterpret_cast<f32x2 *>((conv ? Wbl : Wal) + (tap * 32 + n) * FB_PW + c) = ll;
+  }
+
+  f32x4 pre[FB_NLD];
+  auto tile_coords = [&](int tile, int &img, int &y0, int &x0) {
+    const int tx = tile % p.tiles_x;
+    tile /= p.tiles_x;
+    const int ty = tile % p.tiles_y;
+    img = tile / p.tiles_y;
+    y0 = ty * FB_TR;
+    x0 = tx * FB_TC;
+  };
+  // all patch loads of a tile are issued back to back into registers; converted + written a tile later
+  auto load_patch = [&](int tile) {
+    int img, y0, x0;
+    tile_coords(tile, img, y0, x0);
+    const float *xb = p.x + (long long)img * p.H * p.W * 32;
+#pragma unroll
+    for (int l = 0; l < FB_NLD; ++l) {
+      const int e = tid + 512 * l;
+      const int px = e >> 3, c4 = e & 7;
+      const int pr = px / FB_PC, pc = px - pr * FB_PC;
+      const int iy = y0 - 2 + pr, ix = x0 - 2 + pc;
+      const bool ok = e < FB_PR * FB_PC * 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const long long off = ok ? ((long long)iy * p.W + ix) * 32 + 4 * c4 : 0ll;
+      f32x4 v = *reinterpret_cast<const f32x4 *>(xb + off);
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      pre[l] = v;
+    }
+  };
+  auto write_patch = [&]() {
+#pragma unroll
+    for (int l = 0; l < FB_NLD; ++l) {
+      const int e = tid + 512 * l;
+      if (e < FB_PR * FB_PC * 8) {
+        const int px = e >> 3, c4 = e & 7;
+        const f32x4 v = pre[l];
+        fh4 hi, lo;
+        hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
+        lo.x = (_Float16)(v.x - (float)hi.x); lo.y = (_Float16)(v.y - (float)hi.y);
+        lo.z = (_Float16)(v.z - (float)hi.z); lo.w = (_Float16)(v.w - (float)hi.w);
+        *reinterpret_cast<fh4 *>(Ph + px * FB_PPX + 4 * c4) = hi;
+        *reinterpret_cast<fh4 *>(Pl + px * FB_PPX + 4 * c4) = lo;
+      }
+    }
+  };
+
+  // r = relu(acc * scale + bias) of intermediate pixel (ir, i), zero outside the image, split: registers 4g..4g+3 of the
+  // accumulator = channels 8g + 4h .. +3  ->  four hi and four lo quads
+  auto finish_a = [&](const f32x16 &acc, int ir, int y0, int x0, fh4 (&rh)[4], fh4 (&rl)[4]) {
+    const int y = y0 - 1 + ir, x = x0 - 1 + i;
+    const bool inside = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 8 * g + 4 * h;
+      const f32x4 s4 = *reinterpret_cast<const f32x4 *>(p.sa + c);
+      const f32x4 b4 = p.ba ? *reinterpret_cast<const f32x4 *>(p.ba + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      float v[4];
+      v[0] = __builtin_fmaf(acc[4 * g], s4.x, b4.x); v[1] = __builtin_fmaf(acc[4 * g + 1], s4.y, b4.y);
+      v[2] = __builtin_fmaf(acc[4 * g + 2], s4.z, b4.z); v[3] = __builtin_fmaf(acc[4 * g + 3], s4.w, b4.w);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = inside ? fmaxf(v[j], 0.f) : 0.f;
+        const _Float16 hi = (_Float16)t;
+        rh[g][j] = hi;
+        rl[g][j] = (_Float16)(t - (float)hi);
+      }
+    }
+  };
+  auto write_r = [&](int ir, const fh4 (&rh)[4], const fh4 (&rl)[4]) {
+    const int px = ir * FB_IC + i;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<fh4 *>(Rh + px * FB_PPX + 8 * g + 4 * h) = rh[g];
+      *reinterpret_cast<fh4 *>(Rl + px * FB_PPX + 8 * g + 4 * h) = rl[g];
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < p.n_tiles) { load_patch(tile); write_patch(); }      // (the grid never exceeds the tile count)
+  if (tile + (int)gridDim.x < p.n_tiles) load_patch(tile + gridDim.x);
+  // the two slack pixels behind the intermediate (read by lanes 30 / 31 of an output row, whose results are dropped) hold
+  // whatever patch data lies there: finite fp16 numbers, and an MFMA column only ever mixes data of its own pixel
+  __syncthreads();
+  for (; tile < p.n_tiles; tile += gridDim.x) {
+    int img, y0, x0;
+    tile_coords(tile, img, y0, x0);
+
+    // ---- phase A: intermediate rows `wave` (all waves) and 8 + wave (waves 0, 1)
+    fh4 rh0[4], rl0[4], rh1[4], rl1[4];
+    if (wave < 2) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+      const int rows[2] = {wave, 8 + wave};
+      fb_conv_rows<2>(Ph, Pl, FB_PC, Wah, Wal, rows, i, h, acc);
+      finish_a(acc[0], wave, y0, x0, rh0, rl0);
+      finish_a(acc[1], 8 + wave, y0, x0, rh1, rl1);
+    } else {
+      f32x16 acc[1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+      const int rows[1] = {wave};
+      fb_conv_rows<1>(Ph, Pl, FB_PC, Wah, Wal, rows, i, h, acc);
+      finish_a(acc[0], wave, y0, x0, rh0, rl0);
+    }
+    __syncthreads();                                    // every wave is done reading the input patch
+    write_r(wave, rh0, rl0);
+    if (wave < 2) write_r(8 + wave, rh1, rl1);
+    __syncthreads();
+
+    // ---- phase B: output row `wave`
+    {
+      f32x16 acc[1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+      const int rows[1] = {wave};
+      fb_conv_rows<1>(Rh, Rl, FB_IC, Wbh, Wbl, rows, i, h, acc);
+      const int y = y0 + wave, x = x0 + i;
+      if (i < FB_TC && y < p.H && x < p.W) {
+        const long long pix = ((long long)img * p.H + y) * p.W + x;
+        const float *xp = p.x + pix * 32;
+        float *yp = p.y + pix * 32;
+        f32x4 out[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = 8 * g + 4 * h;
+          const f32x4 s4 = *reinterpret_cast<const f32x4 *>(p.sb + c);
+          const f32x4 b4 = p.bb ? *reinterpret_cast<const f32x4 *>(p.bb + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x4 r4 = *reinterpret_cast<const f32x4 *>(xp + c);
+          f32x4 v;
+          v.x = fmaxf(__builtin_fmaf(acc[0][4 * g], s4.x, b4.x) + r4.x, 0.f);
+          v.y = fmaxf(__builtin_fmaf(acc[0][4 * g + 1], s4.y, b4.y) + r4.y, 0.f);
+          v.z = fmaxf(__builtin_fmaf(acc[0][4 * g + 2], s4.z, b4.z) + r4.z, 0.f);
+          v.w = fmaxf(__builtin_fmaf(acc[0][4 * g + 3], s4.w, b4.w) + r4.w, 0.f);
+          out[g] = v;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(yp + 8 * g + 4 * h) = out[g];
+      }
+    }
+    __syncthreads();                                    // every wave is done reading the intermediate
+    if (tile + (int)gridDim.x < p.n_tiles) write_patch();
+    if (tile + 2 * (int)gridDim.x < p.n_tiles) load_patch(tile + 2 * gridDim.x);
+    __syncthreads();
+  }
+}
+
+// ---- head: 3x3 / pad 1 / 32 -> 1 in exact fp32 ------------------------------------------------------------------------
+constexpr int HD_TR = 8, HD_TC = 32, HD_PR = HD_TR + 2, HD_PC = HD_TC + 2, HD_PITCH = 36;   // floats per patch pixel (32 + 4 pad)
+
+__global__ __launch_bounds__(256) void fusion_head_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                          float *__restrict__ out, int H, int W, int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float patch[HD_PR * HD_PC * HD_PITCH];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int img = t / tiles_y;
+  const float *xb = x + (long long)img * H * W * 32;
+  for (int e = tid; e < HD_PR * HD_PC * 8; e += 256) {
+    const int px = e >> 3, c4 = e & 7;
+    const int pr = px / HD_PC, pc = px - pr * HD_PC;
+    const int iy = ty * HD_TR + pr - 1, ix = tx * HD_TC + pc - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4 *>(xb + ((long long)iy * W + ix) * 32 + 4 * c4);
+    *reinterpret_cast<f32x4 *>(patch + px * HD_PITCH + 4 * c4) = v;
+  }
+  __syncthreads();
+  const int r = tid >> 5, c = tid & 31;
+  const int y = ty * HD_TR + r, xx = tx * HD_TC + c;
+  // four partial sums (taps in OHWI order, channels ascending within a tap) keep the dependent-FMA chains short
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const float *pp = patch + ((r + tap / 3) * HD_PC + c + tap % 3) * HD_PITCH;
+    const float *wt = w + tap * 32;                     // uniform addresses: scalar loads
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(pp + 4 * q);
+      a0 = __builtin_fmaf(v.x, wt[4 * q], a0);
+      a1 = __builtin_fmaf(v.y, wt[4 * q + 1], a1);
+      a2 = __builtin_fmaf(v.z, wt[4 * q + 2], a2);
+      a3 = __builtin_fmaf(v.w, wt[4 * q + 3], a3);
+    }
+  }
+  if (y < H && xx < W) out[((long long)img * H + y) * W + xx] = ((a0 + a1) + (a2 + a3)) + (bias ? bias[0] : 0.f);
+}
+
+static int launch_resblock(const float *x, float *y, const mivos_fusion_layer &a, const mivos_fusion_layer &b, int batch, int H, int W, hipStream_t st) {
+  FuseBlockP p;
+  p.x = x; p.y = y;
+  p.wa = (const float *)a.w16; p.wb = (const float *)b.w16; p.sa = a.scale16; p.sb = b.scale16; p.ba = a.bias; p.bb = b.bias;
+  p.B = batch; p.H = H; p.W = W;
+  p.kpad4 = 80;                                          // K = 9 * 32 = 288 padded to the packer's 64-deep stages: 320 / 4
+  p.tiles_x = cdiv(W, FB_TC); p.tiles_y = cdiv(H, FB_TR);
+  const long long n_tiles = (long long)p.tiles_x * p.tiles_y * batch;
+  if (n_tiles > 0x7fffffffLL) return fail(MIVOS_ERR_INVALID_ARGUMENT, "fusion_resblock: too many tiles");
+  p.n_tiles = (int)n_tiles;
+  const size_t lds = (size_t)FB_LDS_HALVES * 2;
+  static std::atomic<uint64_t> attr_mask{0};
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(fusion_resblock_kernel), lds, attr_mask, "fusion_resblock")) return rc;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+  const int grid = p.n_tiles < cus ? p.n_tiles : cus;   // persistent: one workgroup per CU walks the tiles
+  hipLaunchKernelGGL(fusion_resblock_kernel, dim3(grid), dim3(512), lds, st, p);
+  return check_launch("fusion_resblock");
+}
+
+static int launch_head(const float *x, const float *w, const float *bias, float *out, int batch, int H, int W, hipStream_t st) {
+  const int tiles_x = cdiv(W, HD_TC), tiles_y = cdiv(H, HD_TR);
+  const long long n = (long long)tiles_x * tiles_y * batch;
+  if (n > 0x7fffffffLL) return fail(MIVOS_ERR_INVALID_ARGUMENT, "fusion_head: too many tiles");
+  hipLaunchKernelGGL(fusion_head_kernel, dim3((unsigned)n), dim3(256), 0, st, x, w, bias, out, H, W, tiles_x, tiles_y);
+  return check_launch("fusion_head");
+}
+
+}  // namespace mivos
 
 using namespace mivos;
 
 namespace {
 
-// one precision-1 convolution on dense NHWC tensors
+// one precision-1 convolution on dense NHWC tensors (conv1 of the network)
 int conv(const mivos_fusion_net_desc &d, const mivos_fusion_layer &L, const float *x, int cin, float *y, int cout, int k,
          const float *res, int relu_out, void *stream) {
   mivos_conv_desc c = {};
@@ -26,29 +348,43 @@ int conv(const mivos_fusion_net_desc &d, const mivos_fusion_layer &L, const floa
   return mivos_conv2d_fused(&c, stream);
 }
 
+bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
 }  // namespace
+
+extern "C" int mivos_fusion_resblock(const float *x, float *y, const mivos_fusion_layer *conv_a, const mivos_fusion_layer *conv_b, int batch,
+                                     int height, int width, void *stream) {
+  if (!x || !y || !conv_a || !conv_b || x == y || batch < 1 || height < 1 || width < 1 || !conv_a->w16 || !conv_a->scale16 || !conv_b->w16 ||
+      !conv_b->scale16 || !aligned16(x) || !aligned16(y) || !aligned16(conv_a->w16) || !aligned16(conv_b->w16) || !aligned16(conv_a->scale16) ||
+      !aligned16(conv_b->scale16) || !aligned16(conv_a->bias) || !aligned16(conv_b->bias))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "fusion_resblock: null / misaligned pointer, in-place call or bad sizes");
+  return launch_resblock(x, y, *conv_a, *conv_b, batch, height, width, (hipStream_t)stream);
+}
+
+extern "C" int mivos_fusion_head(const float *x, const float *w_ohwi, const float *bias, float *logits, int batch, int height, int width, void *stream) {
+  if (!x || !w_ohwi || !logits || batch < 1 || height < 1 || width < 1 || !aligned16(x))
+    return fail(MIVOS_ERR_INVALID_ARGUMENT, "fusion_head: null / misaligned pointer or bad sizes");
+  return launch_head(x, w_ohwi, bias, logits, batch, height, width, (hipStream_t)stream);
+}
 
 extern "C" int64_t mivos_fusion_net_scratch_floats(int batch, int height, int width) {
   if (batch < 1 || height < 1 || width < 1) return 0;
-  return 3ll * batch * height * width * 32;
+  return 2ll * batch * height * width * 32;
 }
 
 extern "C" int mivos_fusion_net_forward(const mivos_fusion_net_desc *dp, void *stream) {
   if (!dp) return fail(MIVOS_ERR_INVALID_ARGUMENT, "fusion_net_forward: null descriptor");
   const mivos_fusion_net_desc &d = *dp;
-  if (!d.x16 || !d.logits || !d.scratch || d.batch < 1 || d.height < 1 || d.width < 1)
+  if (!d.x16 || !d.logits || !d.scratch || !d.final_w || d.batch < 1 || d.height < 1 || d.width < 1)
     return fail(MIVOS_ERR_INVALID_ARGUMENT, "fusion_net_forward: null pointer or bad sizes");
   if (d.scratch_floats < mivos_fusion_net_scratch_floats(d.batch, d.height, d.width))
     return fail(MIVOS_ERR_INVALID_ARGUMENT, "fusion_net_forward: scratch too small (mivos_fusion_net_scratch_floats)");
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < 5; ++i)
     if (!d.layer[i].w16 || !d.layer[i].scale16) return fail(MIVOS_ERR_INVALID_ARGUMENT, "fusion_net_forward: layer %d is not packed", i);
   const int64_t plane = (int64_t)d.batch * d.height * d.width * 32;
-  float *A = d.scratch, *B = A + plane, *C = B + plane;
-  if (int rc = conv(d, d.layer[0], d.x16, 16, A, 32, 3, nullptr, 1, stream)) return rc;   // x = relu(conv1(cat))    fusion_net.py:39-40
-  if (int rc = conv(d, d.layer[1], A, 32, B, 32, 3, nullptr, 1, stream)) return rc;       // r = relu(conv2[0](x))
-  if (int rc = conv(d, d.layer[2], B, 32, C, 32, 3, A, 1, stream)) return rc;             // x = relu(x + conv2[2](r))  :42-43
-  if (int rc = conv(d, d.layer[3], C, 32, B, 32, 3, nullptr, 1, stream)) return rc;       // r = relu(conv3[0](x))
-  if (int rc = conv(d, d.layer[4], B, 32, A, 32, 3, C, 1, stream)) return rc;             // x = relu(x + conv3[2](r))  :45-46
-  if (int rc = conv(d, d.layer[5], A, 32, B, 16, 1, nullptr, 0, stream)) return rc;       // nine tap products of final_conv :49
-  return mivos_tap_sum9(B, d.final_bias, d.logits, d.batch, d.height, d.width, stream);
+  float *A = d.scratch, *B = A + plane;
+  if (int rc = conv(d, d.layer[0], d.x16, 16, A, 32, 3, nullptr, 1, stream)) return rc;                     // x = relu(conv1(cat))           fusion_net.py:39-40
+  if (int rc = mivos_fusion_resblock(A, B, &d.layer[1], &d.layer[2], d.batch, d.height, d.width, stream)) return rc;   // x = relu(x + conv2(x))  :42-43
+  if (int rc = mivos_fusion_resblock(B, A, &d.layer[3], &d.layer[4], d.batch, d.height, d.width, stream)) return rc;   // x = relu(x + conv3(x))  :45-46
+  return mivos_fusion_head(A, d.final_w, d.final_bias, d.logits, d.batch, d.height, d.width, stream);     // final_conv               :49
 }

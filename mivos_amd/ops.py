@@ -358,19 +358,25 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
     return (out, out2) if dual else out
 
 
+def _fusion_layer(L):
+    w16, scale16 = L.f16x3()
+    fl = _lib.FusionLayer()
+    fl.w16, fl.scale16, fl.bias = w16.data_ptr(), scale16.data_ptr(), (L.bias.data_ptr() if L.bias is not None else None)
+    return fl
+
+
 def fusion_net_forward(x16, layers, final):
     """FusionNet.forward as one C-ABI call (mivos_fusion_net_forward): x16 [B,H,W,16] fp32, layers = the five packed 3x3
     ConvLayers (conv1[0], conv2[0], conv2[2], conv3[0], conv3[2]), final = final_conv's ConvLayer -> logits [B,H,W,1].
     The f16x3 back-end only (the per-layer path of FusionNet.run serves "f32" and the profiler)."""
     _ensure_device(x16)
     b, h, w, c = x16.shape
-    assert c == 16 and x16.is_contiguous() and CONV_PRECISION == "f16x3"
+    assert c == 16 and x16.is_contiguous() and CONV_PRECISION == "f16x3" and final.cout == 1 and final.cin == 32 and final.scale is None
     lib = _lib.load()
     d = FusionNetDesc()
-    for i, L in enumerate(list(layers) + [final.projection()]):
-        w16, scale16 = L.f16x3()
-        d.layer[i].w16, d.layer[i].scale16 = w16.data_ptr(), scale16.data_ptr()
-        d.layer[i].bias = L.bias.data_ptr() if L.bias is not None else None
+    for i, L in enumerate(layers):
+        d.layer[i] = _fusion_layer(L)
+    d.final_w = final.w.data_ptr()
     d.final_bias = final.bias.data_ptr() if final.bias is not None else None
     out = torch.empty((b, h, w, 1), dtype=torch.float32, device=x16.device)
     n = lib.mivos_fusion_net_scratch_floats(b, h, w)
@@ -380,6 +386,33 @@ def fusion_net_forward(x16, layers, final):
     d.batch, d.height, d.width = b, h, w
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     check(lib.mivos_fusion_net_forward(C.byref(d), _stream()))
+    return out
+
+
+def fusion_resblock(x, conv_a, conv_b, out=None):
+    """relu(x + conv_b(relu(conv_a(x)))) in one launch (mivos_fusion_resblock): x dense fp32 [B,H,W,32], conv_a / conv_b
+    packed 3x3 / pad 1 ConvLayers 32 -> 32 without BN scale."""
+    _ensure_device(x)
+    b, h, w, c = x.shape
+    assert c == 32 and x.is_contiguous() and x.dtype == torch.float32
+    for L in (conv_a, conv_b):
+        assert (L.cin, L.cout, L.k, L.stride, L.pad, L.dil) == (32, 32, 3, 1, 1, 1) and L.scale is None
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.shape == x.shape and out.is_contiguous() and out.data_ptr() != x.data_ptr()
+    la, lb = _fusion_layer(conv_a), _fusion_layer(conv_b)
+    check(_lib.load().mivos_fusion_resblock(x.data_ptr(), out.data_ptr(), C.byref(la), C.byref(lb), b, h, w, _stream()))
+    return out
+
+
+def fusion_head(x, final):
+    """final_conv of FusionNet (3x3, pad 1, 32 -> 1) in exact fp32 (mivos_fusion_head): x [B,H,W,32] -> [B,H,W,1]."""
+    _ensure_device(x)
+    b, h, w, c = x.shape
+    assert c == 32 and x.is_contiguous() and final.cout == 1 and final.cin == 32 and final.k == 3 and final.scale is None
+    out = torch.empty((b, h, w, 1), dtype=torch.float32, device=x.device)
+    check(_lib.load().mivos_fusion_head(x.data_ptr(), final.w.data_ptr(), final.bias.data_ptr() if final.bias is not None else None,
+                                        out.data_ptr(), b, h, w, _stream()))
     return out
 
 
