@@ -44,7 +44,7 @@ VARIANT_NAMES = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<64,6
                  18: "conv_f16x3_pipe_kernel<64,256,2,4>", 19: "conv3x3_n32_direct_kernel",
                  20: "conv_f16x3_pp_kernel<128,128,2,4,0>", 21: "conv_f16x3_pp_kernel<128,256,2,4,0>",
                  22: "conv_f16x3_pp_kernel<128,64,4,2,0>", 23: "conv_f16x3_pp_kernel<256,256,2,4,0>",
-                 30: "fusion_net_kernel", 90: "memread_select_kernel", 91: "memread_finalize_kernel"}
+                 30: "fusion_net_forward (conv1 + 2 x fusion_resblock_kernel + fusion_head_kernel)", 90: "memread_select_kernel", 91: "memread_finalize_kernel"}
 CONFIGS = {
     2: dict(name="davis480p_single_object", height=480, width=854, frames=70, objects=1, top_k=20, interactions=(0,)),
     3: dict(name="davis480p_multiobject_fusion", height=480, width=854, frames=70, objects=5, top_k=50, interactions=(0, -1)),
@@ -138,7 +138,9 @@ def kernel_rooflines(samples, overhead=0.0, config=3, select_kernel=None):
         a[0] += flops
         a[1] += max(e0.elapsed_time(e1) * 1e-3 - overhead, 1e-7)
         a[2] += 1
-        if variant < 90:
+        if variant == 30:
+            a[3] += shape[-1]
+        elif variant < 90:
             m, cin, cout, k, stride, has_res = shape
             # one read of the input, the weights and the residual, one write of the output (4 B per element)
             a[3] += 4.0 * m * stride * stride * cin + 4.0 * cout * k * k * cin + 4.0 * m * cout * (2 if has_res else 1)

@@ -82,7 +82,8 @@ typedef struct {
   int64_t res_nstride, res_pstride; /* res_nstride == 0 broadcasts one residual over the batch   */
   void *workspace;         /* optional device scratch for split-K (small-M layers: K is cut into slices whose
                               fp32 partial tiles are summed in a fixed order by a second kernel: deterministic);
-                              NULL or too small = no split-K                                              */
+                              NULL or too small = no split-K; not to be shared by calls running concurrently
+                              on two streams                                                               */
   int64_t workspace_bytes;
   /* Row strides in floats; 0 = dense rows (W resp. Wo pixels apart).  A non-dense row stride is how a tensor
    * stored with a border of zero pixels is addressed: x / y / res point at interior pixel (0, 0) of image 0. */
@@ -162,7 +163,8 @@ int mivos_tap_sum9(const float *t, const float *bias, float *out, int N, int H, 
  * layer[0..4] = conv1[0], conv2[0], conv2[2], conv3[0], conv3[2] (3x3) as the precision-1 operands of mivos_conv2d_fused
  * (w16 from mivos_pack_weights_f16x3, scale16 = 2^-s per output channel, bias or NULL); final_w = final_conv.weight as
  * fp32 OHWI [1][3][3][32], final_bias = its bias (one float) or NULL.
- * Launches on `stream`: conv1 (the library's direct 3x3 kernel), mivos_fusion_resblock twice, mivos_fusion_head.
+ * Launches on `stream`: conv1 (mivos_fusion_conv1_planes, or the library's direct 3x3 kernel on x16), mivos_fusion_resblock twice,
+ * mivos_fusion_head.
  * scratch: mivos_fusion_net_scratch_floats() floats of device memory; workspace: unused split-K scratch of conv1 (may be NULL).
  *
  * mivos_fusion_resblock - one residual block of the network in ONE launch (fusion_net.py:42-43 / :45-46):
@@ -170,12 +172,15 @@ int mivos_tap_sum9(const float *t, const float *bias, float *out, int N, int H, 
  *   the intermediate never leaves LDS; arithmetic = the f16x3 convolutions of mivos_conv2d_fused (same products, same order).
  * mivos_fusion_head - final_conv (3x3, pad 1, 32 -> 1; fusion_net.py:49) in exact fp32: x [batch][H][W][32] -> logits [batch][H*W].
  * -------------------------------------------------------------------------------------------- */
+struct mivos_interleave_desc_s;
 typedef struct { const void *w16; const float *scale16; const float *bias; } mivos_fusion_layer;
 typedef struct {
   mivos_fusion_layer layer[5];
   const float *final_w;        /* final_conv.weight, fp32 OHWI [1][3][3][32] */
   const float *final_bias;     /* final_conv.bias (one float) or NULL */
-  const float *x16;
+  const float *x16;            /* the interleaved input, or NULL when `planes` is given */
+  const struct mivos_interleave_desc_s *planes;   /* the nine planar inputs (channel c of sample n = plane[c] + n*nstride[c], NULL
+                                                     plane = the constant cval[c]): conv1 gathers them itself, no x16 tensor */
   float *logits;
   float *scratch;
   int64_t scratch_floats;
@@ -189,6 +194,37 @@ int mivos_fusion_resblock(const float *x, float *y, const mivos_fusion_layer *co
                           int height, int width, void *stream);
 int mivos_fusion_head(const float *x, const float *w_ohwi, const float *bias, float *logits, int batch, int height, int width,
                       void *stream);
+/* conv1 of the network (9 -> 32, 3x3, ReLU; fusion_net.py:38-40) straight from the planar inputs: y [batch][H][W][32]. */
+int mivos_fusion_conv1_planes(const struct mivos_interleave_desc_s *planes, const mivos_fusion_layer *conv1, float *y, int batch,
+                              int height, int width, void *stream);
+
+/* --------------------------------------------------------------------------------------------
+ * FusionNet training step (model/fusion_model.py:54-131 FusionModel.do_pass; model/losses.py:21-76; train.py:96-124).
+ * The forward pass and the data gradients are mivos_conv2d_fused / mivos_fusion_* launches (dgrad of a 3x3 convolution =
+ * the 3x3 convolution with transposed, 180-degree-rotated weights); these entry points are the rest of the step:
+ *   mivos_fusion_wgrad3x3   dw[n][tap][c] = sum_pixels g[p][n] * x[p + tap][c] (OHWI, like the weights), db[n] = sum_pixels g[p][n]
+ *                           for a 3x3 / pad 1 / stride 1 convolution; x [N][H][W][cx] (cx 16 or 32), g [N][H][W][cg] (cg 32 or 1),
+ *                           dense fp32; exact fp32 MFMA, fixed summation order (deterministic); scratch:
+ *                           mivos_fusion_wgrad_scratch_floats() floats
+ *   mivos_fusion_loss       z1, z2 [B][P] (FusionNet logits of object 1 / 2), selector [B][2], cls_gt [B][P] int32 ->
+ *                           logits [B][3][P], mask [B][3][P] (aggregate_wbg_channel of sigmoid(z) * selector, aggregate.py:39-53),
+ *                           loss [B][P] = per-pixel cross-entropy (3 classes if selector[b][1] > 0.5, else classes {0, 1})
+ *   mivos_fusion_kth_loss   BootstrappedCE's top-k: out4[b] = {k[b]-th largest of loss[b][:], #(loss > it), sum(loss > it), #(loss == it)}
+ *   mivos_fusion_loss_grad  d total_loss / d z1, d z2 for per-sample pixel weights wsel[b] = {tau, w(loss > tau), w(loss == tau)}
+ *   mivos_mul_positive      g[i] = y[i] > 0 ? g[i] : 0 (ReLU backward), n % 4 == 0
+ *   mivos_adam_step         torch.optim.Adam (betas, eps, L2 weight_decay, bias correction for `step` >= 1) on flat fp32 vectors
+ * -------------------------------------------------------------------------------------------- */
+int64_t mivos_fusion_wgrad_scratch_floats(void);
+int mivos_fusion_wgrad3x3(const float *x, int cx, const float *g, int cg, float *dw_ohwi, float *db, float *scratch,
+                          int64_t scratch_floats, int N, int H, int W, void *stream);
+int mivos_fusion_loss(const float *z1, const float *z2, const float *selector, const int32_t *cls_gt, float *logits, float *mask,
+                      float *loss, int B, int64_t P, void *stream);
+int mivos_fusion_kth_loss(const float *loss, const int32_t *k, float *out4, int B, int64_t P, void *stream);
+int mivos_fusion_loss_grad(const float *z1, const float *z2, const float *selector, const int32_t *cls_gt, const float *loss,
+                           const float *wsel, float *dz1, float *dz2, int B, int64_t P, void *stream);
+int mivos_mul_positive(float *g, const float *y, int64_t n, void *stream);
+int mivos_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, int step, void *stream);
 
 /* --------------------------------------------------------------------------------------------
  * Space-time memory read: affinity (MFMA) -> streaming per-query top-k -> softmax over the k
@@ -316,7 +352,7 @@ int mivos_mask_others(const float *masks, float *others, int K, int64_t P, void 
 /* Interleave up to 16 planar sources into dense NHWC [N][P][C] (torch.cat along channels of
  * modules.py:54 and fusion_net.py:38, plus zero padding of the channel dimension).
  * channel c of batch n reads plane[c] + n*nstride[c] (NULL plane: the constant cval[c]). */
-typedef struct {
+typedef struct mivos_interleave_desc_s {
   const float *plane[16];
   int64_t nstride[16];
   float cval[16];

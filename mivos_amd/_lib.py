@@ -38,7 +38,7 @@ class FusionLayer(C.Structure):
 
 class FusionNetDesc(C.Structure):
     """mivos_fusion_net_desc"""
-    _fields_ = [("layer", FusionLayer * 5), ("final_w", vp), ("final_bias", vp), ("x16", vp), ("logits", vp), ("scratch", vp),
+    _fields_ = [("layer", FusionLayer * 5), ("final_w", vp), ("final_bias", vp), ("x16", vp), ("planes", vp), ("logits", vp), ("scratch", vp),
                 ("scratch_floats", i64), ("batch", i32), ("height", i32), ("width", i32), ("workspace", vp),
                 ("workspace_bytes", i64)]
 
@@ -53,6 +53,14 @@ PROTOTYPES = {
     "mivos_fusion_net_forward": (C.c_int, [C.POINTER(FusionNetDesc), vp]),
     "mivos_fusion_resblock": (C.c_int, [vp, vp, C.POINTER(FusionLayer), C.POINTER(FusionLayer), C.c_int, C.c_int, C.c_int, vp]),
     "mivos_fusion_head": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_fusion_conv1_planes": (C.c_int, [C.POINTER(InterleaveDesc), C.POINTER(FusionLayer), vp, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_fusion_wgrad_scratch_floats": (i64, []),
+    "mivos_fusion_wgrad3x3": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_fusion_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, i64, vp]),
+    "mivos_fusion_kth_loss": (C.c_int, [vp, vp, vp, C.c_int, i64, vp]),
+    "mivos_fusion_loss_grad": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, i64, vp]),
+    "mivos_mul_positive": (C.c_int, [vp, vp, i64, vp]),
+    "mivos_adam_step": (C.c_int, [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, vp]),
     "mivos_pack_weights_f16x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "mivos_pack_activation_sh32": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_unpack_activation_sh32": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

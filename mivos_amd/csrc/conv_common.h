@@ -242,6 +242,36 @@ __device__ __forceinline__ void epilogue_sh32(const f32x16 (&acc)[MT][NT], float
   }
 }
 
+// split-K: output element group (pixel m, channels n..n+3) = act(sum_s partial[s] * scale + bias + res), slices summed in
+// ascending order (deterministic whichever workgroup does it)
+__device__ __forceinline__ void splitk_finish4(const ConvP &p, int n_slices, int m, int n) {
+  const int c4n = p.Cout >> 2;
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(p.partial + (long long)m * p.Cout + n);
+  f32x4 v = src[0];
+  for (int s = 1; s < n_slices; ++s) {
+    const f32x4 t = src[(long long)s * p.M * c4n];
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  const int img = m / p.HoWo, pix = m - img * p.HoWo;
+  const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
+  if (p.scale) { const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + n); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+  if (p.bias) { const f32x4 bi = *reinterpret_cast<const f32x4 *>(p.bias + n); v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
+  if (p.res) {
+    const long long ro = (long long)img * p.r_ns + (long long)oh * p.r_rs + (long long)ow * p.r_ps;
+    const f32x4 rr = p.r_fmt ? load_sh32x4(p.res, ro, n) : *reinterpret_cast<const f32x4 *>(p.res + ro + n);
+    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+  }
+  if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  float *dst;
+  long long d_ns, d_rs, d_ps;
+  int dn, d_fmt;
+  if (n < p.split) { dst = p.y; d_ns = p.y_ns; d_rs = p.y_rs; d_ps = p.y_ps; dn = n; d_fmt = p.y_fmt; }
+  else { dst = p.y2; d_ns = p.y2_ns; d_rs = p.y2_rs; d_ps = p.y2_ps; dn = n - p.split; d_fmt = 0; }
+  const long long yo = (long long)img * d_ns + (long long)oh * d_rs + (long long)ow * d_ps;
+  if (d_fmt) store_sh32x4(dst, yo, dn, v);
+  else *reinterpret_cast<f32x4 *>(dst + yo + dn) = v;
+}
+
 // fills ConvP from the public descriptor after validating it; returns a status code
 int conv_params_from_desc(const mivos_conv_desc *d, ConvP &p);
 int launch_conv_f16x3(ConvP &p, hipStream_t st);

@@ -243,6 +243,9 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
     q.y = p.partial + (long long)blockIdx.y * p.M * p.Cout;
     q.y_ps = p.Cout; q.y_rs = (long long)p.Wo * p.Cout; q.y_ns = (long long)p.HoWo * p.Cout; q.y_fmt = 0;
     epilogue_vec<MT, NT>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, q, m0 + wm * TM, n0 + wn * TN, lane);
+    // (the partial tiles are summed by splitk_reduce_kernel.  Summing them here - the last slice of a tile to arrive, found
+    // with a per-tile arrival counter - was built and measured in round 3: the release fence every workgroup needs before it
+    // counts itself writes back its XCD's whole L2, and config 3 fell from 192.6 to 132.8 frames/s.)
     return;
   }
   // tiles that fit two workgroups per CU (<= 80 KB LDS) must also stay within 128 VGPRs: prefetch one row tile at a time

@@ -116,6 +116,7 @@ class InferenceCore:
         self.interacted = set()
         self._certain_k = self._certain_v = None     # [K, n, h, w, C] rows per memory position
         self.propagated_frames = 0                   # do_pass iterations so far (the bench metric)
+        self._fuse_stream, self._fuse_pending = None, []
 
     # ---- reference-shaped views of the certain memory -------------------------------------
     @property
@@ -176,6 +177,30 @@ class InferenceCore:
     def get_query_kv_buffered(self, idx):
         return self._query(idx).as_reference_tuple()
 
+    # Fusion of frame ti only feeds self.prob[:, ti]; the propagation chain (memorize -> next frame's read) never looks at it
+    # (reference inference_core.py:186-197: the frame is memorised from the UNFUSED mask).  With everything resident in HBM the
+    # fusion launches therefore go to a second HIP stream behind an event and run beside the next memorize / decode launches:
+    # FusionNet is HBM-bound, the encoder GEMMs are matrix-core bound.  Same kernels, same arithmetic, same results.
+    FUSE_ON_SIDE_STREAM = os.environ.get("MIVOS_FUSE_SIDE_STREAM", "1") != "0"
+
+    def _fuse_async(self, closest, idx, ti, out, key_k, q):
+        main = torch.cuda.current_stream()
+        if self._fuse_stream is None:
+            self._fuse_stream = torch.cuda.Stream(device=self.device)
+        side = self._fuse_stream
+        ready = torch.cuda.Event()
+        ready.record(main)
+        out.record_stream(side)                       # allocated on the main stream, last read on the side stream
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            self.prob[:, ti] = self.fuse_one_frame(closest, idx, ti, self.prob[:, ti], out, key_k, q.k16)
+        self._fuse_pending.append((out, q))           # keep the operands alive until the streams have joined
+
+    def _join_fusion(self):
+        if self._fuse_pending:
+            torch.cuda.current_stream().wait_stream(self._fuse_stream)
+            self._fuse_pending = []
+
     # ---- one propagation pass ---------------------------------------------------------------
     def do_pass(self, key_k, key_v, idx, forward=True, step_cb=None):
         """key_k: keys of the interacted frame, rows layout [K, h*w, 128] (used by the fusion attention)."""
@@ -205,12 +230,16 @@ class InferenceCore:
                                             key_out=keys[:, st.slot], val_out=values[:, st.slot])
                 if ksplit is not None:
                     ops.split_keys(keys[:, st.slot], ksplit[:, st.slot])
-            if st.fuse:
-                out = self.fuse_one_frame(closest, idx, st.ti, self.prob[:, st.ti], out, key_k, q.k16)
-            self.prob[:, st.ti] = out.to(self.result_dev)
+            if st.fuse and self.FUSE_ON_SIDE_STREAM and self.result_dev == self.device:
+                self._fuse_async(closest, idx, st.ti, out, key_k, q)
+            else:
+                if st.fuse:
+                    out = self.fuse_one_frame(closest, idx, st.ti, self.prob[:, st.ti], out, key_k, q.k16)
+                self.prob[:, st.ti] = out.to(self.result_dev)
             self.propagated_frames += 1
             if step_cb is not None:
                 step_cb()
+        self._join_fusion()
         return closest
 
     @_on_core_device
@@ -231,9 +260,8 @@ class InferenceCore:
         curr = curr_mask.to(self.device)
         im = self.get_image_buffered(ti).contiguous()
         prev_k, curr_k = prev[1:], curr[1:]
-        x = self.fuse_net.pack_inputs((im, 0), (prev_k, prev_k.stride(0)), (curr_k, curr_k.stride(0)),
-                                      (attn, 2 * P), (nc, nr), K)
-        w = ops.sigmoid(self.fuse_net.run(x))                                               # [K,nh,nw,1]
+        w = ops.sigmoid(self.fuse_net.run_planes((im, 0), (prev_k, prev_k.stride(0)), (curr_k, curr_k.stride(0)),
+                                                 (attn, 2 * P), (nc, nr), K))               # [K,nh,nw,1]
         return ops.aggregate(w.view(K, 1, self.nh, self.nw), keep_bg=True)
 
     # ---- public entry points ------------------------------------------------------------------

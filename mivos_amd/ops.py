@@ -365,27 +365,51 @@ def _fusion_layer(L):
     return fl
 
 
-def fusion_net_forward(x16, layers, final):
-    """FusionNet.forward as one C-ABI call (mivos_fusion_net_forward): x16 [B,H,W,16] fp32, layers = the five packed 3x3
-    ConvLayers (conv1[0], conv2[0], conv2[2], conv3[0], conv3[2]), final = final_conv's ConvLayer -> logits [B,H,W,1].
-    The f16x3 back-end only (the per-layer path of FusionNet.run serves "f32" and the profiler)."""
-    _ensure_device(x16)
-    b, h, w, c = x16.shape
-    assert c == 16 and x16.is_contiguous() and CONV_PRECISION == "f16x3" and final.cout == 1 and final.cin == 32 and final.scale is None
+def fusion_net_forward(x16, layers, final, planes=None, shape=None):
+    """FusionNet.forward as one C-ABI call (mivos_fusion_net_forward): x16 [B,H,W,16] fp32 - or, instead, the nine planar inputs
+    `planes` = [(tensor_or_float, batch_stride)] x 9 with shape = (B, H, W): conv1 then gathers them itself and no x16 tensor
+    exists; layers = the five packed 3x3 ConvLayers (conv1[0], conv2[0], conv2[2], conv3[0], conv3[2]), final = final_conv's
+    ConvLayer -> logits [B,H,W,1].  The f16x3 back-end only (FusionNet.run(layered=True) serves "f32")."""
+    if planes is not None:
+        b, h, w = shape
+        pd, keep = _interleave_desc(planes, 16)
+        assert len(planes) == 9
+        dev = final.w.device
+    else:
+        _ensure_device(x16)
+        b, h, w, c = x16.shape
+        assert c == 16 and x16.is_contiguous()
+        dev = x16.device
+    assert CONV_PRECISION == "f16x3" and final.cout == 1 and final.cin == 32 and final.scale is None
     lib = _lib.load()
     d = FusionNetDesc()
     for i, L in enumerate(layers):
         d.layer[i] = _fusion_layer(L)
     d.final_w = final.w.data_ptr()
     d.final_bias = final.bias.data_ptr() if final.bias is not None else None
-    out = torch.empty((b, h, w, 1), dtype=torch.float32, device=x16.device)
+    out = torch.empty((b, h, w, 1), dtype=torch.float32, device=dev)
     n = lib.mivos_fusion_net_scratch_floats(b, h, w)
-    scratch = _workspace(4 * n, x16.device, "fusion_net")
-    ws = _workspace(SPLITK_WORKSPACE_BYTES, x16.device)
-    d.x16, d.logits, d.scratch, d.scratch_floats = _f32(x16).data_ptr(), out.data_ptr(), scratch.data_ptr(), n
+    scratch = _workspace(4 * n, dev, "fusion_net")
+    ws = _workspace(SPLITK_WORKSPACE_BYTES, dev)
+    if planes is not None:
+        d.x16, d.planes = None, C.cast(C.pointer(pd), C.c_void_p)
+    else:
+        d.x16, d.planes = _f32(x16).data_ptr(), None
+    d.logits, d.scratch, d.scratch_floats = out.data_ptr(), scratch.data_ptr(), n
     d.batch, d.height, d.width = b, h, w
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     check(lib.mivos_fusion_net_forward(C.byref(d), _stream()))
+    return out
+
+
+def fusion_conv1_planes(planes, shape, conv1):
+    """conv1 of FusionNet (9 -> 32, ReLU) straight from the nine planar inputs (mivos_fusion_conv1_planes) -> [B,H,W,32]."""
+    b, h, w = shape
+    pd, keep = _interleave_desc(planes, 16)
+    assert len(planes) == 9 and (conv1.cin, conv1.cout, conv1.k) == (16, 32, 3)
+    la = _fusion_layer(conv1)
+    out = torch.empty((b, h, w, 32), dtype=torch.float32, device=conv1.w.device)
+    check(_lib.load().mivos_fusion_conv1_planes(C.byref(pd), C.byref(la), out.data_ptr(), b, h, w, _stream()))
     return out
 
 
@@ -414,6 +438,77 @@ def fusion_head(x, final):
     check(_lib.load().mivos_fusion_head(x.data_ptr(), final.w.data_ptr(), final.bias.data_ptr() if final.bias is not None else None,
                                         out.data_ptr(), b, h, w, _stream()))
     return out
+
+
+# ---- FusionNet training step (csrc/fusion_train.hip; reference model/fusion_model.py:54-131, model/losses.py) -----------------
+
+def fusion_wgrad3x3(x, g):
+    """Weight / bias gradient of a 3x3, pad 1, stride 1 convolution y = conv(x): x [N,H,W,cx] (cx 16 / 32), g = dL/dy [N,H,W,cg]
+    (cg 32 / 1), dense fp32 -> (dw OHWI [cg,3,3,cx], db [cg]).  Exact fp32 MFMA, deterministic."""
+    _ensure_device(x)
+    n, h, w, cx = x.shape
+    cg = g.shape[3]
+    assert x.is_contiguous() and g.is_contiguous() and g.shape[:3] == x.shape[:3] and x.dtype == g.dtype == torch.float32
+    lib = _lib.load()
+    dw = torch.empty((cg, 3, 3, cx), dtype=torch.float32, device=x.device)
+    db = torch.empty((cg,), dtype=torch.float32, device=x.device)
+    nf = lib.mivos_fusion_wgrad_scratch_floats()
+    scratch = _workspace(4 * nf, x.device, "wgrad")
+    check(lib.mivos_fusion_wgrad3x3(x.data_ptr(), cx, g.data_ptr(), cg, dw.data_ptr(), db.data_ptr(), scratch.data_ptr(), nf, n, h, w, _stream()))
+    return dw, db
+
+
+def fusion_loss(z1, z2, selector, cls_gt):
+    """z1, z2 [B,P] FusionNet logits of object 1 / 2, selector [B,2], cls_gt [B,P] int32 -> (logits [B,3,P], mask [B,3,P] =
+    aggregate_wbg_channel(sigmoid(z) * selector, keep_bg=True), per-pixel cross-entropy [B,P])."""
+    _ensure_device(z1)
+    b, p = z1.shape
+    z1, z2, selector = _f32(z1).contiguous(), _f32(z2).contiguous(), _f32(selector).contiguous()
+    assert cls_gt.dtype == torch.int32 and cls_gt.is_contiguous() and cls_gt.shape == (b, p) and selector.shape == (b, 2)
+    logits = torch.empty((b, 3, p), dtype=torch.float32, device=z1.device)
+    mask, loss = torch.empty_like(logits), torch.empty((b, p), dtype=torch.float32, device=z1.device)
+    check(_lib.load().mivos_fusion_loss(z1.data_ptr(), z2.data_ptr(), selector.data_ptr(), cls_gt.data_ptr(), logits.data_ptr(), mask.data_ptr(),
+                                        loss.data_ptr(), b, p, _stream()))
+    return logits, mask, loss
+
+
+def fusion_kth_loss(loss, k):
+    """loss [B,P], k [B] int32 -> [B,4] = (k-th largest, #(loss > it), sum(loss > it), #(loss == it)) per sample."""
+    _ensure_device(loss)
+    b, p = loss.shape
+    assert loss.is_contiguous() and k.dtype == torch.int32 and k.shape == (b,)
+    out = torch.empty((b, 4), dtype=torch.float32, device=loss.device)
+    check(_lib.load().mivos_fusion_kth_loss(loss.data_ptr(), k.data_ptr(), out.data_ptr(), b, p, _stream()))
+    return out
+
+
+def fusion_loss_grad(z1, z2, selector, cls_gt, loss, wsel):
+    """d total_loss / d z1, d z2 [B,P]; wsel [B,3] = (tau, weight of a pixel with loss > tau, weight of a pixel with loss == tau)."""
+    _ensure_device(z1)
+    b, p = z1.shape
+    z1, z2, selector, wsel = _f32(z1).contiguous(), _f32(z2).contiguous(), _f32(selector).contiguous(), _f32(wsel).contiguous()
+    assert wsel.shape == (b, 3) and loss.is_contiguous() and cls_gt.dtype == torch.int32
+    dz1, dz2 = torch.empty_like(z1), torch.empty_like(z1)
+    check(_lib.load().mivos_fusion_loss_grad(z1.data_ptr(), z2.data_ptr(), selector.data_ptr(), cls_gt.data_ptr(), loss.data_ptr(), wsel.data_ptr(),
+                                             dz1.data_ptr(), dz2.data_ptr(), b, p, _stream()))
+    return dz1, dz2
+
+
+def mul_positive(g, y):
+    """In place g *= (y > 0): ReLU backward."""
+    _ensure_device(g)
+    assert g.is_contiguous() and y.is_contiguous() and g.shape == y.shape and g.dtype == y.dtype == torch.float32
+    check(_lib.load().mivos_mul_positive(g.data_ptr(), y.data_ptr(), g.numel(), _stream()))
+    return g
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, step):
+    """torch.optim.Adam's update on flat fp32 vectors (in place)."""
+    _ensure_device(param)
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.numel() == param.numel()
+    check(_lib.load().mivos_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(), float(lr),
+                                      float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), _stream()))
 
 
 def maxpool3x3s2(x, act_tag=None, as_act=False):
@@ -737,9 +832,8 @@ def mask_others(masks):
     return out
 
 
-def interleave(planes, n, p, c_out, device):
-    """planes: list of (tensor_or_float, batch_stride) per channel (missing channels up to c_out are
-    zero) -> dense NHWC [n, p, c_out].  A float entry is a constant plane."""
+def _interleave_desc(planes, c_out):
+    """mivos_interleave_desc of a plane list [(tensor_or_float, batch_stride), ...] (+ the tensors to keep alive)."""
     d = InterleaveDesc()
     d.C = c_out
     keep = []
@@ -753,6 +847,13 @@ def interleave(planes, n, p, c_out, device):
             assert src.dtype == torch.float32
             keep.append(src)
             d.plane[c], d.nstride[c] = src.data_ptr(), ns
+    return d, keep
+
+
+def interleave(planes, n, p, c_out, device):
+    """planes: list of (tensor_or_float, batch_stride) per channel (missing channels up to c_out are
+    zero) -> dense NHWC [n, p, c_out].  A float entry is a constant plane."""
+    d, keep = _interleave_desc(planes, c_out)
     out = torch.empty((n, p, c_out), dtype=torch.float32, device=device)
     check(_lib.load().mivos_interleave_planes(C.byref(d), out.data_ptr(), n, p, _stream()))
     return out

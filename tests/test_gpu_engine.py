@@ -181,23 +181,23 @@ def test_segment_with_query_public_api_vs_oracle(nets, synthetic_states):
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 48, 80), (5, 480, 864), (2, 37, 61)])
-def test_fusion_net_forward_entry_equals_the_layer_by_layer_path(nets, B, H, W):
-    """mivos_fusion_net_forward (one C-ABI call per FusionNet forward) issues the launches of FusionNet.run's
-    layer-by-layer path: bit-identical logits, on the benchmark's batch (5 objects at 480x864) and on ragged sizes."""
-    from mivos_amd import ops
+def test_fusion_net_forward_entry_vs_the_layer_by_layer_path(nets, B, H, W):
+    """mivos_fusion_net_forward (one C-ABI call per FusionNet forward): conv1 + two fused residual-block launches +
+    the exact-fp32 head, against FusionNet.run(layered=True) = the six convolutions of fusion_net.py:32-50 issued one by one
+    (the path the golden vector of the reference pins); on the benchmark's batch (5 objects at 480x864) and on ragged sizes.
+    The residual blocks use the same products in the same order (rounding-level agreement); the head is exact fp32 instead
+    of f16x3 (~1e-6 of the logit range)."""
     _, fuse = nets
     g = torch.Generator().manual_seed(B * 1000 + H)
     x = torch.zeros(B, H, W, 16)
     x[..., :9] = torch.randn(B, H, W, 9, generator=g)
     x = x.to(DEV)
     one_call = fuse.run(x)
-    old, ops.PROFILE = ops.PROFILE, []                 # the profiler's path: every convolution its own call
-    try:
-        layered = fuse.run(x)
-    finally:
-        ops.PROFILE = old
-    assert one_call.shape == layered.shape == (B, H, W, 1)
-    assert torch.equal(one_call, layered) and bool(torch.isfinite(one_call).all())
+    layered = fuse.run(x, layered=True)
+    assert one_call.shape == layered.shape == (B, H, W, 1) and bool(torch.isfinite(one_call).all())
+    d = float((one_call - layered).abs().max())
+    print(f"FusionNet one call vs layer by layer [{B}x{H}x{W}]: max|dlogit| {d:.2e} on logits up to {float(layered.abs().max()):.2f}")
+    assert d < 2e-5 * max(1.0, float(layered.abs().max()))
 
 
 def test_fusion_generator_call_pattern_vs_oracle(nets, synthetic_states):

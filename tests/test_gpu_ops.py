@@ -267,6 +267,83 @@ def test_conv_rejects_bad_arguments():
         ops.conv(torch.zeros(1, 8, 8, 16), ConvLayer.pack(torch.randn(8, 16, 3, 3), None, None, 1, 1))  # CPU tensor
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 8, 30), (1, 9, 31), (2, 37, 61), (1, 48, 80), (5, 480, 864), (1, 16, 1000)])
+def test_fusion_resblock_one_launch_vs_two_convolutions(B, H, W):
+    """mivos_fusion_resblock: relu(x + conv_b(relu(conv_a(x)))) with the intermediate in LDS (csrc/fusion_net.hip), against the
+    two fused-epilogue convolutions of the layer-by-layer path (same f16x3 products in the same order: agreement at rounding
+    level, any tile / halo / zero-padding indexing error is O(1)) and against fp64 torch.  Sizes: one tile exactly, one pixel
+    more than a tile each way, ragged, the benchmark's batch, a wide strip (34 tiles across)."""
+    g = torch.Generator().manual_seed(B * 7919 + H * 31 + W)
+    x = torch.randn(B, 32, H, W, generator=g)
+    wa, wb = (torch.randn(32, 32, 3, 3, generator=g) * (2.0 / 288) ** 0.5 for _ in range(2))
+    ba, bb = (torch.randn(32, generator=g) * 0.1 for _ in range(2))
+    La, Lb = ConvLayer.pack(wa, ba, None, 1, 1).to(DEV), ConvLayer.pack(wb, bb, None, 1, 1).to(DEV)
+    xd = nhwc(x).to(DEV)
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f16x3"
+    try:
+        got = ops.fusion_resblock(xd, La, Lb)
+        two = ops.conv(ops.conv(xd, La, relu_out=True), Lb, res=xd, relu_out=True)
+        nobias = ops.fusion_resblock(xd, ConvLayer.pack(wa, None, None, 1, 1).to(DEV), ConvLayer.pack(wb, None, None, 1, 1).to(DEV))
+    finally:
+        ops.CONV_PRECISION = old
+    ref = F.relu(x.double() + F.conv2d(F.relu(F.conv2d(x.double(), wa.double(), ba.double(), padding=1)), wb.double(), bb.double(), padding=1))
+    ref0 = F.relu(x.double() + F.conv2d(F.relu(F.conv2d(x.double(), wa.double(), None, padding=1)), wb.double(), None, padding=1))
+    d2 = float((got - two).abs().max())
+    print(f"fusion_resblock [{B}x{H}x{W}]: vs two launches {d2:.2e}, vs fp64 {rel_err(got.cpu().permute(0, 3, 1, 2), ref):.2e} (two launches: {rel_err(two.cpu().permute(0, 3, 1, 2), ref):.2e})")
+    assert got.shape == (B, H, W, 32) and d2 < 1e-5
+    assert rel_err(got.cpu().permute(0, 3, 1, 2), ref) < 3e-6 and rel_err(nobias.cpu().permute(0, 3, 1, 2), ref0) < 3e-6
+    with pytest.raises(AssertionError):
+        ops.fusion_resblock(xd, La, Lb, out=xd)                                # in place is refused
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 8, 32), (3, 37, 61), (5, 480, 864)])
+def test_fusion_conv1_from_planes(B, H, W):
+    """mivos_fusion_conv1_planes (conv1 of FusionNet gathering its nine planar inputs itself, fusion_net.py:38-40) against the
+    interleave + direct-convolution path: shared image planes (batch stride 0), per-object planes, a strided two-plane
+    tensor and two constant planes - the operands InferenceCore.fuse_one_frame passes."""
+    g = torch.Generator().manual_seed(B * 13 + W)
+    P = H * W
+    im = torch.randn(3, H, W, generator=g).to(DEV)
+    s1, s2 = torch.rand(B, 1, H, W, generator=g).to(DEV), torch.rand(B, 1, H, W, generator=g).to(DEV)
+    attn = torch.rand(2 * B, H, W, generator=g).to(DEV)
+    w, b = torch.randn(32, 9, 3, 3, generator=g) * (2.0 / 81) ** 0.5, torch.randn(32, generator=g) * 0.1
+    L = ConvLayer.pack(w, b, None, 1, 1, cin_pad=16).to(DEV)
+    imf, atf = im.reshape(-1), attn.reshape(-1)
+    planes = [(imf[c * P:], 0) for c in range(3)] + [(s1, P), (s2, P)] + [(atf[c * P:], 2 * P) for c in range(2)] + [(0.25, 0), (0.75, 0)]
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f16x3"
+    try:
+        got = ops.fusion_conv1_planes(planes, (B, H, W), L)
+        ref = ops.conv(ops.interleave(planes, B, P, 16, im.device).view(B, H, W, 16), L, relu_out=True)
+    finally:
+        ops.CONV_PRECISION = old
+    x = torch.cat([im.cpu().expand(B, -1, -1, -1), s1.cpu(), s2.cpu(), attn.cpu().view(B, 2, H, W), torch.full((B, 1, H, W), 0.25), torch.full((B, 1, H, W), 0.75)], 1)
+    ref64 = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    assert got.shape == (B, H, W, 32) and float((got - ref).abs().max()) < 1e-5
+    assert rel_err(got.cpu().permute(0, 3, 1, 2), ref64) < 3e-6
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 8, 32), (2, 37, 61), (5, 480, 864)])
+def test_fusion_head_exact_fp32(B, H, W):
+    """mivos_fusion_head (final_conv 32 -> 1, fusion_net.py:49) in exact fp32 FMA vs fp64 torch and vs the f16x3 projection +
+    tap-sum path it replaces."""
+    g = torch.Generator().manual_seed(B * 31 + W)
+    x = torch.randn(B, 32, H, W, generator=g)
+    w, b = torch.randn(1, 32, 3, 3, generator=g) * (2.0 / 288) ** 0.5, torch.randn(1, generator=g)
+    L = ConvLayer.pack(w, b, None, 1, 1).to(DEV)
+    xd = nhwc(x).to(DEV)
+    got = ops.fusion_head(xd, L)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f16x3"
+    try:
+        proj = ops.conv(xd, L)
+    finally:
+        ops.CONV_PRECISION = old
+    assert got.shape == (B, H, W, 1) and rel_err(got.cpu().permute(0, 3, 1, 2), ref) < 1e-6
+    assert float((got - proj).abs().max()) < 1e-5 * float(ref.abs().max())
+    nb = ops.fusion_head(xd, ConvLayer.pack(w, None, None, 1, 1).to(DEV))
+    assert rel_err(nb.cpu().permute(0, 3, 1, 2), ref - b.double()) < 1e-6
+
+
 def test_maxpool_and_upsample_add():
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 64, 37, 45, generator=g)

@@ -158,3 +158,27 @@ def test_s2m_network(golden_dir):
     m[0, 0, 4, 4] = m[0, 0, 0, 8] = 1
     d = SO.dilate3x3(m)
     assert d.sum() == 9 + 4 and d[0, 0, 3:6, 3:6].min() == 1            # 3x3 max filter, zero outside the image
+
+
+def test_train_step_oracle_matches_the_reference(golden_dir):
+    """oracle/train_oracle.py (the checker of the GPU training-step tests at sizes the fixture does not hold) against
+    tests/golden/train_small.npz = the unmodified reference's FusionNet / aggregate_wbg_channel / LossComputer / Adam on the
+    same batch, before, inside and after BootstrappedCE's warm-up."""
+    from oracle import train_oracle as TO
+    with np.load(os.path.join(golden_dir, "train_small.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    cfg = json.loads(str(g["config"]))
+    data = {k[3:]: T(v) for k, v in g.items() if k.startswith("in.")}
+    fsd = Wt.make_fuse_state(0)
+    for it in cfg["its"]:
+        tag = f"it{it}."
+        with torch.enable_grad():
+            r = TO.train_step(fsd, data, T(g[tag + "attn1"]), T(g[tag + "attn2"]), it, cfg["iterations"], cfg["lr"])
+        assert float((r["logits"] - T(g[tag + "logits"])).abs().max()) <= 1e-5
+        assert float((r["mask"] - T(g[tag + "mask"])).abs().max()) <= 1e-6
+        assert abs(r["total_loss"] - float(g[tag + "total_loss"])) <= 1e-6 * max(1.0, abs(float(g[tag + "total_loss"])))
+        assert abs(r["p"] - float(g[tag + "p"])) <= 1e-12
+        for n in fsd:
+            ref = T(g[tag + "grad." + n])
+            assert float((r["grads"][n] - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (it, n)
+            assert float((r["new"][n] - T(g[tag + "new." + n])).abs().max()) <= 2e-6, (it, n)       # updates are ~lr = 1e-4
