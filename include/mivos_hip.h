@@ -198,6 +198,17 @@ int mivos_fusion_head(const float *x, const float *w_ohwi, const float *bias, fl
 int mivos_fusion_conv1_planes(const struct mivos_interleave_desc_s *planes, const mivos_fusion_layer *conv1, float *y, int batch,
                               int height, int width, void *stream);
 
+/* Full-softmax read: PropagationNetwork(top_k=None), the reference's "no top-k" configuration (prop_net.py:99-102: softmax over
+ * ALL memory positions; :104-108 mem = mv @ affinity).  One pass with a running (max, denominator, numerator) per query, both
+ * products on exact fp32 MFMA; same operands as mivos_memory_read_topk; the result goes to `out` rows (may be NULL) and / or to the
+ * SH32 activation buffers raw_sh32 / relu_sh32 (x and relu(x), addressed like mivos_memory_read_finalize_sh32; may be NULL).
+ * workspace: mivos_memory_read_dense_workspace_bytes() bytes (per-segment partial results). */
+int64_t mivos_memory_read_dense_workspace_bytes(int n_obj, int64_t n_mem, int n_q);
+int mivos_memory_read_dense(const float *keys, int64_t keys_ostride, const float *values, int64_t values_ostride, const float *qk,
+                            float *out, int64_t out_ostride, int64_t out_pstride, void *raw_sh32, void *relu_sh32, int64_t a_nstride,
+                            int64_t a_rstride, int64_t a_pstride, int q_width, int n_obj, int64_t n_mem, int n_q, void *workspace,
+                            int64_t workspace_bytes, void *stream);
+
 /* --------------------------------------------------------------------------------------------
  * FusionNet training step (model/fusion_model.py:54-131 FusionModel.do_pass; model/losses.py:21-76; train.py:96-124).
  * The forward pass and the data gradients are mivos_conv2d_fused / mivos_fusion_* launches (dgrad of a 3x3 convolution =

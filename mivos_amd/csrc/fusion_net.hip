@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512) void fusion_resblock_kernel(const FuseBlockP p
 // shared by all objects and stay in L2), split to fp16 hi / lo into a [pixel][16 + 8] LDS image whose channels 9..15 stay
 // zero, and multiplied exactly like conv3x3_n32_direct_kernel<16> (same products, same order: bit-identical output).
 constexpr int C1_TR = 8, C1_TC = 32, C1_PR = 10, C1_PC = 34, C1_PPX = 24, C1_PW = 24, C1_NPX = C1_PR * C1_PC;
-constexpr int C1_NLD = (C1_NPX * 9 + 511) / 512;
+static_assert(C1_NPX <= 512, "one thread per patch pixel");
 
 struct FuseConv1P {
   const float *plane[9];
@@ -314,7 +314,6 @@ __global__ __launch_bounds__(512) void fusion_conv1_kernel(const FuseConv1P p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
 
-  for (int e = tid; e < 4 * IMG / 2; e += 512) reinterpret_cast<uint32_t *>(P0)[e] = 0u;     // channels 9..15 (and the pad) stay zero
   for (int e = tid; e < 32 * 36; e += 512) {                   // weights: [32][kpad4 = 48] float4, 36 real quads (K = 144)
     const int n = e / 36, q = e - n * 36;
     const f32x4 v = reinterpret_cast<const f32x4 *>(p.w)[(long long)n * 48 + q];
@@ -325,9 +324,11 @@ __global__ __launch_bounds__(512) void fusion_conv1_kernel(const FuseConv1P p) {
     *reinterpret_cast<f32x2 *>(Wh + (tap * 32 + n) * C1_PW + c) = hh;
     *reinterpret_cast<f32x2 *>(Wl + (tap * 32 + n) * C1_PW + c) = ll;
   }
-  __syncthreads();                                             // (the zero fill precedes the first patch write)
 
-  float pre[C1_NLD];
+  // thread t < 340 owns patch pixel t: nine plane reads (neighbouring threads read neighbouring pixels of the same plane; the
+  // plane index is a compile-time constant - a run-time index into the by-value parameter block would put it into scratch
+  // memory), then the pixel's 16 hi and 16 lo halves (channels 9..15 zero) go to LDS as four 16-byte stores
+  float pre[9];
   auto tile_coords = [&](int tile, int &img, int &y0, int &x0) {
     const int tx = tile % p.tiles_x;
     tile /= p.tiles_x;
@@ -339,32 +340,33 @@ __global__ __launch_bounds__(512) void fusion_conv1_kernel(const FuseConv1P p) {
   auto load_patch = [&](int tile) {
     int img, y0, x0;
     tile_coords(tile, img, y0, x0);
+    const int pr = tid / C1_PC, pc = tid - pr * C1_PC;
+    const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+    const bool ok = tid < C1_NPX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const long long pix = ok ? (long long)iy * p.W + ix : 0ll;
 #pragma unroll
-    for (int l = 0; l < C1_NLD; ++l) {
-      const int e = tid + 512 * l;
-      const int c = e / C1_NPX, px = e - c * C1_NPX;           // plane-major: neighbouring lanes read neighbouring pixels of one plane
-      const int pr = px / C1_PC, pc = px - pr * C1_PC;
-      const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+    for (int c = 0; c < 9; ++c) {
+      const float *src = p.plane[c];
       float v = 0.f;
-      if (c < 9 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-        const float *src = p.plane[c];
-        v = src ? src[(long long)img * p.nstride[c] + (long long)iy * p.W + ix] : p.cval[c];
-      }
-      pre[l] = v;
+      if (ok) v = src ? src[(long long)img * p.nstride[c] + pix] : p.cval[c];
+      pre[c] = v;                                              // (outside the image every channel is zero: the padding of the concatenation)
     }
   };
   auto write_patch = [&](_Float16 *Ph) {
-    _Float16 *Pl = Ph + IMG;
+    if (tid < C1_NPX) {
+      _Float16 *Pl = Ph + IMG;
+      fh8 h0, l0, h1 = {0, 0, 0, 0, 0, 0, 0, 0}, l1 = h1;
 #pragma unroll
-    for (int l = 0; l < C1_NLD; ++l) {
-      const int e = tid + 512 * l;
-      const int c = e / C1_NPX, px = e - c * C1_NPX;
-      if (c < 9) {
-        const float v = pre[l];
-        const _Float16 hi = (_Float16)v;
-        Ph[px * C1_PPX + c] = hi;
-        Pl[px * C1_PPX + c] = (_Float16)(v - (float)hi);
+      for (int c = 0; c < 8; ++c) {
+        h0[c] = (_Float16)pre[c];
+        l0[c] = (_Float16)(pre[c] - (float)h0[c]);
       }
+      h1[0] = (_Float16)pre[8];
+      l1[0] = (_Float16)(pre[8] - (float)h1[0]);
+      *reinterpret_cast<fh8 *>(Ph + tid * C1_PPX) = h0;
+      *reinterpret_cast<fh8 *>(Ph + tid * C1_PPX + 8) = h1;
+      *reinterpret_cast<fh8 *>(Pl + tid * C1_PPX) = l0;
+      *reinterpret_cast<fh8 *>(Pl + tid * C1_PPX + 8) = l1;
     }
   };
 

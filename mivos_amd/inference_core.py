@@ -142,10 +142,17 @@ class InferenceCore:
     # 8 keeps the look-ahead inside bench.py's default 8 warm-up steps, so no timed frame is encoded before the clock starts
     QUERY_BATCH = int(os.environ.get("MIVOS_QUERY_BATCH", "8"))
 
+    def _encode(self, todo):
+        if len(todo) == 1:
+            return [self.prop_net.encode_query(self.get_image_buffered(todo[0]))]
+        return self.prop_net.encode_query_batch(torch.cat([self.get_image_buffered(t) for t in todo], 0))
+
     def _query(self, idx, upcoming=()):
         """Cached query features of frame idx.  On a miss the next not-yet-cached frames of the running pass
         (`upcoming`, in processing order) are encoded in the same batch: the features are state independent,
-        so this is the reference's lazy cache (:110-120) filled a few frames ahead."""
+        so this is the reference's lazy cache (:110-120) filled a few frames ahead.
+        (Encoding the NEXT batch on the side stream while the current one is consumed was built and measured in round 3:
+        +0.8 % on the full config-3 session, -4 % on a 20-step window that starts with an empty cache; not kept.)"""
         q = self.query_buf.get(idx)
         if q is None:
             if len(self.query_buf) > self.q_buf_size:
@@ -153,14 +160,10 @@ class InferenceCore:
             room = self.q_buf_size + 1 - len(self.query_buf)
             todo = [idx] + [t for t in upcoming if t != idx and t not in self.query_buf]
             todo = todo[:max(1, min(self.QUERY_BATCH, room))]
-            if len(todo) == 1:
-                q = self.query_buf[idx] = self.prop_net.encode_query(self.get_image_buffered(idx))
-            else:
-                frames = torch.cat([self.get_image_buffered(t) for t in todo], 0)
-                for t, qt in zip(todo, self.prop_net.encode_query_batch(frames)):
-                    self.query_buf[t] = qt
-                self._lookahead.update(todo[1:])
-                q = self.query_buf[idx]
+            for t, qt in zip(todo, self._encode(todo)):
+                self.query_buf[t] = qt
+            self._lookahead.update(todo[1:])
+            q = self.query_buf[idx]
         self._lookahead.discard(idx)
         return q
 

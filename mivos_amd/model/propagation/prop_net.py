@@ -110,9 +110,9 @@ MAX_TOP_K = 64      # csrc/memory_read.hip: candidate lists are sized for k <= 6
 class PropagationNetwork(PlanCache):
     def __init__(self, top_k=50):
         super().__init__()
-        if top_k is None or not (1 <= int(top_k) <= MAX_TOP_K):
-            raise MivosHipError(f"PropagationNetwork(top_k={top_k}): the MI355X memory-read kernel supports 1 <= top_k <= "
-                                f"{MAX_TOP_K} (reference default 50); top_k=None (full softmax over the bank) is not implemented")
+        if top_k is not None and not (1 <= int(top_k) <= MAX_TOP_K):
+            raise MivosHipError(f"PropagationNetwork(top_k={top_k}): the MI355X top-k memory-read kernels support 1 <= top_k <= "
+                                f"{MAX_TOP_K} (reference default 50), or top_k=None = softmax over the whole bank (prop_net.py:99-102)")
         self.mask_rgb_encoder = MaskRGBEncoder()
         self.rgb_encoder = RGBEncoder()
         self.kv_m_f16 = KeyValue(1024, keydim=CK, valdim=CV)

@@ -616,8 +616,6 @@ def _memread_args(keys, values, qk, top_k):
     if values is not None:
         values, vo = _rows(_f32(values), 512)
         assert values.shape[:2] == (k, n_mem)
-    if top_k is None:
-        raise MivosHipError("memory_read: top_k=None (full softmax) is not part of the propagation path")
     return keys, ko, values, vo, k, n_mem, n_q
 
 
@@ -630,13 +628,18 @@ def _memread_profile(ev, k, n_mem, n_q, top_k, out_rows):
 def memory_read(keys, values, qk, top_k, out=None, keys_split=None):
     """keys [K, n_mem, 128], values [K, n_mem, 512], qk [n_q, 128] -> out [K, n_q, 512]
     (out may be a channel-slice view [K, n_q, 512] of a wider [K, n_q, C] buffer).  keys_split: split_keys(keys) kept by the
-    caller (otherwise converted here on every call)."""
+    caller (otherwise converted here on every call).  top_k=None: softmax over all memory positions (exact fp32)."""
     _ensure_device(keys)
     keys, ko, values, vo, k, n_mem, n_q = _memread_args(keys, values, qk, top_k)
     if out is None:
         out = torch.empty((k, n_q, 512), dtype=torch.float32, device=keys.device)
     assert out.shape == (k, n_q, 512) and out.stride(2) == 1
     lib = _lib.load()
+    if top_k is None:            # full softmax over the bank (PropagationNetwork(top_k=None), prop_net.py:99-102)
+        ws = _workspace(lib.mivos_memory_read_dense_workspace_bytes(k, n_mem, n_q), keys.device, "memread_dense")
+        check(lib.mivos_memory_read_dense(keys.data_ptr(), ko, values.data_ptr(), vo, qk.data_ptr(), out.data_ptr(), out.stride(0), out.stride(1),
+                                          None, None, 0, 0, 0, 1, k, n_mem, n_q, ws.data_ptr(), ws.numel(), _stream()))
+        return out
     ws = _workspace(lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k), keys.device, "memread")
     ev = None
     if PROFILE is not None:      # bench.py: HIP events on the launch stream around each of the two launches
@@ -662,8 +665,13 @@ def memory_read_acts(keys, values, qk, top_k, h, w, tag="memread", keys_split=No
     assert n_q == h * w
     raw, rel = alloc_act(k, h, w, 512, keys.device, (tag, "raw")), alloc_act(k, h, w, 512, keys.device, (tag, "relu"))
     lib = _lib.load()
-    ws = _workspace(lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k), keys.device, "memread")
     an, ar, ap = raw.strides()
+    if top_k is None:
+        ws = _workspace(lib.mivos_memory_read_dense_workspace_bytes(k, n_mem, n_q), keys.device, "memread_dense")
+        check(lib.mivos_memory_read_dense(keys.data_ptr(), ko, values.data_ptr(), vo, qk.data_ptr(), None, 0, 0, raw.interior_ptr(), rel.interior_ptr(),
+                                          an, ar, ap, w, k, n_mem, n_q, ws.data_ptr(), ws.numel(), _stream()))
+        return raw, rel
+    ws = _workspace(lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k), keys.device, "memread")
     ev = None
     if PROFILE is not None:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]

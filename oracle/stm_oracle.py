@@ -403,5 +403,52 @@ class OracleCore:
         self.np_masks = out.numpy().astype(np.uint8)
         return self.np_masks
 
+class OracleGenerator:
+    """Restatement of FusionGenerator (generation/fusion_generator.py:12-101): propagation from one annotated frame to both range
+    limits, no fusion, no query cache; the bank grows by torch.cat with a temporary entry for the previous frame."""
+
+    def __init__(self, sd, images, mem_freq, top_k=50, dtype=torch.float32):
+        self.sd, self.mem_freq, self.top_k, self.dtype = sd, mem_freq, top_k, dtype
+        self.t = images.shape[1]
+        self.h, self.w = images.shape[-2:]
+        self.images, self.pad = pad_divide_by(images.to(dtype), 16)                       # :22
+        self.nh, self.nw = self.images.shape[-2:]
+
+    def reset(self, k):                                                                    # :32-34
+        self.k = k
+        self.prob = torch.zeros((k + 1, self.t, 1, self.nh, self.nw), dtype=self.dtype)
+
+    def do_pass(self, key_k, key_v, idx, left_limit, right_limit, forward=True):            # :43-78
+        keys, values = key_k, key_v
+        prev_k = prev_v = None
+        last_ti = idx
+        if forward:
+            rng, end = range(idx + 1, right_limit + 1), right_limit
+        else:
+            rng, end = range(idx - 1, left_limit - 1, -1), left_limit
+        for ti in rng:
+            this_k = keys if prev_k is None else torch.cat([keys, prev_k], 2)
+            this_v = values if prev_v is None else torch.cat([values, prev_v], 2)
+            q = get_query_values(self.sd, self.images[:, ti])
+            out = aggregate_wbg(segment_with_query(self.sd, this_k, this_v, *q, top_k=self.top_k), keep_bg=True)
+            self.prob[:, ti] = out
+            if ti != end:
+                prev_k, prev_v = memorize(self.sd, self.images[:, ti], out[1:])
+                if abs(ti - last_ti) >= self.mem_freq:
+                    last_ti = ti
+                    keys, values = torch.cat([keys, prev_k], 2), torch.cat([values, prev_v], 2)
+                    prev_k = prev_v = None
+
+    def interact_mask(self, mask, idx, left_limit, right_limit):                           # :80-101
+        mask, _ = pad_divide_by(mask.to(self.dtype), 16)
+        mask = aggregate_wbg(mask, keep_bg=True)
+        self.prob[:, idx] = mask
+        key_k, key_v = memorize(self.sd, self.images[:, idx], mask[1:])
+        self.do_pass(key_k, key_v, idx, left_limit, right_limit, True)
+        self.do_pass(key_k, key_v, idx, left_limit, right_limit, False)
+        lw, uw, lh, uh = self.pad
+        return self.prob[:, :, 0, lh:self.nh - uh, lw:self.nw - uw]
+
+
 # ------------------------------------------------------------------ synthetic clips
 from mivos_amd.util.synthetic import synthetic_clip  # noqa: E402,F401  (shared input generator)

@@ -396,6 +396,26 @@ def test_callbacks_and_single_frame_clip(nets):
     assert np.array_equal(m[0], gt1[0].argmax(0)[0].numpy().astype(np.uint8))
 
 
+def test_no_topk_network_closed_loop_vs_oracle(synthetic_states):
+    """PropagationNetwork(top_k=None) - the reference's full-softmax reader (prop_net.py:99-102, README's "no top-k" row) - through
+    InferenceCore: 4 frames at 240x432, 2 objects, interact(0) then interact(3) (frames 1, 2 fused), against the oracle with
+    top_k=None in fp32 and fp64 (fp64-arbitrated gate).  No top-k membership to flip: the two fp32 runs stay at rounding level."""
+    sd, fsd = synthetic_states
+    prop, fuse = PropagationNetwork(top_k=None), FusionNet()
+    prop.load_state_dict(sd)
+    fuse.load_state_dict(fsd)
+    images, gt = O.synthetic_clip(4, 240, 432, 2, seed=91)
+    core = InferenceCore(prop.to(DEV).eval(), fuse.to(DEV).eval(), images, 2, mem_freq=2, device=DEV)
+    o32 = O.OracleCore(sd, fsd, images, 2, mem_freq=2, top_k=None)
+    o64 = O.OracleCore(sd, fsd, images, 2, mem_freq=2, top_k=None, dtype=torch.float64)
+    for idx in (0, 3):
+        out, r32, _ = core.interact(gt[idx], idx), o32.interact(gt[idx], idx), o64.interact(gt[idx], idx)
+        assert mean_iou(out, r32, 2) >= 0.999
+        ok, rec = fp64_gate(f"no_topk_closed_loop[interact({idx})]", core.prob, o32.prob, o64.prob)
+        assert ok, rec
+    assert core.propagated_frames == o32.propagated == 5
+
+
 def test_topk_larger_than_memory_raises_like_reference(nets):
     """64x96 frame -> 24 memory positions at T=1 < top_k=50: the reference dies in torch.topk
     ('selected index k out of range'); so do we (SURVEY.md §7 hard part 2)."""

@@ -520,6 +520,31 @@ def test_memory_read_deep_bank_1080p_vs_chunked_oracle(frames, scale):
     assert int(idx.min()) >= 0 and int(idx.max()) < frames * hw
 
 
+@pytest.mark.parametrize("T,h,w,K", [(1, 8, 10, 1), (3, 9, 13, 2), (5, 30, 54, 3), (7, 30, 54, 5), (2, 68, 120, 1)])
+def test_memory_read_full_softmax_vs_oracle(T, h, w, K):
+    """top_k=None (prop_net.py:99-102, the reference's "no top-k" configuration): one-pass softmax over all memory positions +
+    readout on exact fp32 MFMA (csrc/memory_read_dense.hip) vs the oracle's materialised F.softmax(affinity) @ values in fp64 and
+    fp32; fp32 rows and the SH32 activation outputs of the decoder path; ragged tiles (T*h*w not a multiple of 16), several
+    memory segments per query tile, the 480p benchmark shape and the 1080p grid."""
+    mk, mv, qk = _mem_case(T, h, w, K, seed=900 + T * 10 + K, scale=1.5)
+    keys = mk.permute(0, 2, 3, 4, 1).reshape(K, T * h * w, 128).contiguous().to(DEV)
+    vals = mv.permute(0, 2, 3, 4, 1).reshape(K, T * h * w, 512).contiguous().to(DEV)
+    q = qk.permute(0, 2, 3, 1).reshape(h * w, 128).contiguous().to(DEV)
+    got = ops.memory_read(keys, vals, q, None)
+    ref64 = torch.cat([O.memory_read(mk[o:o + 1].double(), mv[o:o + 1].double(), qk.double(), None) for o in range(K)], 0)
+    ref32 = torch.cat([O.memory_read(mk[o:o + 1], mv[o:o + 1], qk, None) for o in range(K)], 0)
+    g = got.cpu().view(K, h, w, 512).permute(0, 3, 1, 2)
+    e64, r64 = float((g.double() - ref64).abs().max()), float((ref32.double() - ref64).abs().max())
+    print(f"full softmax T={T} {h}x{w} K={K}: max|d| vs fp64 {e64:.2e} (torch fp32 vs fp64: {r64:.2e}), readout range {float(ref64.abs().max()):.2f}")
+    assert e64 < 2e-5 * max(1.0, float(ref64.abs().max()))
+    raw, rel = ops.memory_read_acts(keys, vals, q, None, h, w, tag="test.dense")
+    assert float((ops.to_f32(raw) - got.view(K, h, w, 512)).abs().max()) < 1e-5 * max(1.0, float(got.abs().max()))
+    assert float((ops.to_f32(rel) - got.view(K, h, w, 512).clamp(min=0)).abs().max()) < 1e-5 * max(1.0, float(got.abs().max()))
+    m4 = torch.full((K, h * w, 1024), 7.0, device=DEV)
+    ops.memory_read(keys, vals, q, None, out=m4[:, :, :512])                     # channel-slice destination
+    assert torch.equal(m4[:, :, :512], got) and float((m4[:, :, 512:] - 7).abs().max()) == 0
+
+
 def test_memory_read_sharp_scores_and_ties(mem_precision):
     # large-magnitude keys (softmax nearly one-hot) and duplicated memory rows (exact score ties)
     mk, mv, qk = _mem_case(2, 8, 10, 1, seed=9, scale=6.0)

@@ -182,3 +182,16 @@ def test_train_step_oracle_matches_the_reference(golden_dir):
             ref = T(g[tag + "grad." + n])
             assert float((r["grads"][n] - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (it, n)
             assert float((r["new"][n] - T(g[tag + "new." + n])).abs().max()) <= 2e-6, (it, n)       # updates are ~lr = 1e-4
+
+
+def test_generator_oracle_matches_the_reference(golden_dir, synthetic_states):
+    """oracle.OracleGenerator vs tests/golden/gen_small.npz (the unmodified generation/fusion_generator.py, oracle/make_golden_gen.py)."""
+    with np.load(os.path.join(golden_dir, "gen_small.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    c = json.loads(str(g["config"]))
+    images, gt = O.synthetic_clip(c["t"], c["h"], c["w"], c["k"], c["seed"])
+    gen = O.OracleGenerator(synthetic_states[0], images, c["mem_freq"], top_k=c["top_k"])
+    for n, (idx, left, right) in enumerate(c["calls"]):
+        gen.reset(c["k"])
+        out = gen.interact_mask(gt[idx, 1:], idx, left, right)
+        assert out.shape == g[f"prob_{n}"].shape and float((out - T(g[f"prob_{n}"])).abs().max()) <= TOL
