@@ -313,6 +313,9 @@ def main():
     ap.add_argument("--top-k", type=int, default=None)
     ap.add_argument("--mem-freq", type=int, default=5)
     ap.add_argument("--clips", type=int, default=48, help="config 4: how many of the 474 suite clips to run (474 = all)")
+    ap.add_argument("--generator", action="store_true",
+                    help="config 4 as the offline fusion-data generator (generate_fusion.py:68-120): every 5th frame of a clip is a reference "
+                         "frame whose masks are propagated to both ends of the clip (FusionGenerator), sharded over the ranks like the suite")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the CPU-oracle mini session (0 = skip; default 4, config 5: 2)")
     ap.add_argument("--no-cpu-fp64", dest="cpu_fp64", action="store_false",
                     help="skip the fp64 run of the oracle on the mini session (the arbitration truth of the parity block; ~4x the fp32 oracle's time)")
@@ -440,6 +443,8 @@ def bench_suite(args, torch, ops, shard, rank, world, dev):
     fuse.load_state_dict(synthetic.make_fuse_state(0))
     prop, fuse = prop.to(dev).eval(), fuse.to(dev).eval()
     specs = ES.synthetic_suite(474)[:args.clips]
+    if args.generator:
+        return bench_generator(args, torch, shard, ES, specs, prop, rank, world, dev)
 
     def factory(spec):
         images, gt = synthetic.synthetic_clip_device(spec.frames, spec.height, spec.width, spec.objects, seed=spec.seed, device=dev)
@@ -469,6 +474,38 @@ def bench_suite(args, torch, ops, shard, rank, world, dev):
                     baseline_config=4, clips=len(specs), parallelism=f"sequence-sharded x{world}", suite_checksum=s["checksum"]),
         roofline=None, cpu_baseline=None, wall_seconds=round(elapsed, 3), busiest_rank_engine_seconds=round(s["busiest_rank_seconds"], 3),
         per_rank=sorted(per_rank.values(), key=lambda r: r["rank"]))))
+
+
+def bench_generator(args, torch, shard, ES, specs, prop, rank, world, dev):
+    """--config 4 --generator: the second caller of the network API as a batch workload."""
+    from mivos_amd.generation.fusion_generator import FusionGenerator
+    from mivos_amd.util import synthetic
+
+    def factory(spec):
+        images, gt = synthetic.synthetic_clip_device(spec.frames, spec.height, spec.width, spec.objects, seed=spec.seed, device=dev)
+        return FusionGenerator(prop, images, args.mem_freq), gt[:, 1:]
+
+    ES.run_generator_suite([ES.ClipSpec(-1, 10, 2, 480, 853, 7)], factory, 0, 1, sync=torch.cuda.synchronize)       # warm-up clip (untimed)
+    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    recs = ES.run_generator_suite(specs, factory, rank, world, sync=torch.cuda.synchronize)
+    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
+    allrecs = shard.gather_records(recs)
+    if rank != 0:
+        return
+    s = ES.summarize(allrecs, len(specs))
+    print(json.dumps(dict(
+        metric="propagated frames/sec, fusion-data generator over a YouTube-VOS-like suite sharded over the GPUs", value=round(s["frames"] / elapsed, 3),
+        unit="frames/s", n_gpus=world, steps=s["frames"], warmup=18, ms_per_step=round(elapsed / s["frames"] * 1e3, 3), higher_is_better=True,
+        scaling="strong", vs_baseline=None,
+        dtype="f16x3 convolutions and memory-read affinity (fp16 hi+lo split operands, 3 fp16 MFMA products per term, fp32 accumulate)", data="synthetic",
+        config=dict(workload=f"fusion_data_generator (generate_fusion.py:68-120 on BASELINE config 4's suite): first {len(specs)} of 474 synthetic clips, every "
+                             f"5th frame a reference frame propagated to both ends of its clip, no fusion; query features cached per clip; clips assigned "
+                             f"longest-first to {world} rank(s), no data-path collective; clip generation + uint8 egress inside the timed region",
+                    baseline_config=4, clips=len(specs), reference_frames=sum(r["reference_frames"] for r in allrecs),
+                    parallelism=f"sequence-sharded x{world}", suite_checksum=s["checksum"]),
+        roofline=None, cpu_baseline=None, wall_seconds=round(elapsed, 3), busiest_rank_engine_seconds=round(s["busiest_rank_seconds"], 3))))
 
 
 if __name__ == "__main__":

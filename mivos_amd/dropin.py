@@ -7,7 +7,8 @@
 (`eval_interactive_davis.py:11-15`, `interactive_gui.py:29-35`, `davis_processor.py:7-9`):
 
     inference_core, davis_processor, model.propagation.prop_net, model.propagation.modules, model.fusion_net,
-    model.aggregate, model.attn_network, model.s2m.s2m_network, util.tensor_util
+    model.aggregate, model.attn_network, model.s2m.s2m_network, util.tensor_util,
+    generation.fusion_generator (generate_fusion.py:16), model.fusion_model (train.py:14)
 
 Everything else of the reference (``interact``, ``dataset``, ``model.s2s`` ...) keeps resolving to the reference
 tree, which is appended to the package search paths of ``model`` / ``util``.
@@ -27,9 +28,11 @@ ALIASES = {
     "model.s2m.s2m_network": "mivos_amd.model.s2m.s2m_network",
     "davis_processor": "mivos_amd.davis_processor",
     "util.tensor_util": "mivos_amd.util.tensor_util",
+    "generation.fusion_generator": "mivos_amd.generation.fusion_generator",      # generate_fusion.py:16
+    "model.fusion_model": "mivos_amd.model.fusion_model",                        # train.py:14
 }
 PACKAGES = {"model": "mivos_amd.model", "model.propagation": "mivos_amd.model.propagation", "model.s2m": "mivos_amd.model.s2m",
-            "util": "mivos_amd.util"}
+            "util": "mivos_amd.util", "generation": "mivos_amd.generation"}
 
 
 def install(reference_root=None):

@@ -71,6 +71,46 @@ def run_suite(specs, engine_factory, rank=0, world=1, sync=None, on_clip=None):
     return records
 
 
+def generator_cost(n_frames, n_objects, separation):
+    """Relative cost of a clip in generator mode: one two-sided propagation over the clip per reference frame."""
+    return len(range(0, n_frames, separation)) * shard.clip_cost(n_frames - 1, n_objects)
+
+
+def run_generator_suite(specs, generator_factory, rank=0, world=1, separation=5, max_objects=5, sync=None, on_result=None):
+    """The offline fusion-data generator (reference generate_fusion.py:68-120) over this rank's share of `specs`: for every
+    `separation`-th frame of a clip, the frame's ground-truth masks of the usable objects (more than 10 x 10 pixels, at most
+    `max_objects`: generate_fusion.py:83-91) are propagated to both ends of the clip (DAVIS ranges, :100-102) and the soft
+    probabilities come back as uint8 maps (:109).  ``generator_factory(spec) -> (generator, gt)`` with gt [T,K,1,H,W] float
+    masks (objects only) and generator a FusionGenerator over the clip.  Records: one per clip, `frames` = propagated frames."""
+    parts = shard.assign_sequences([generator_cost(s.frames, s.objects, separation) for s in specs], world)
+    records = []
+    for i in parts[rank]:
+        spec = specs[i]
+        gen, gt = generator_factory(spec)
+        if sync:
+            sync()
+        t0 = time.perf_counter()
+        crc, frames, refs = 0, 0, 0
+        for frame in range(0, spec.frames, separation):
+            usable = [k for k in range(gt.shape[1]) if float((gt[frame, k] > 0.5).sum()) > 100][:max_objects]
+            if not usable:
+                continue
+            gen.reset(len(usable))
+            probs = gen.interact_mask(gt[frame, usable], frame, 0, spec.frames - 1)          # [K+1, T, H, W]
+            out = np.asarray((probs[1:] * 255).to("cpu").numpy() if hasattr(probs, "to") else probs[1:] * 255).astype(np.uint8)
+            crc = zlib.crc32(np.ascontiguousarray(out).tobytes(), crc)
+            frames += spec.frames - 1
+            refs += 1
+            if on_result is not None:
+                on_result(spec, frame, usable, out)
+        if sync:
+            sync()
+        records.append(dict(clip=spec.clip_id, rank=rank, frames=frames, objects=spec.objects, reference_frames=refs,
+                            seconds=time.perf_counter() - t0, checksum=int(crc)))
+        del gen
+    return records
+
+
 def summarize(all_records, n_specs=None):
     """Aggregate of the gathered records of all ranks: every clip exactly once, total propagated frames, the busiest
     rank's time (what bounds the wall clock of the sharded run) and the imbalance of the assignment."""

@@ -29,22 +29,14 @@ from .util.tensor_util import pad_divide_by
 Step = namedtuple("Step", "ti n_read slot fuse")
 
 
-def plan_pass(t, interacted, idx, forward, mem_freq, n_certain):
-    """Schedule of one propagation pass (reference: do_pass, inference_core.py:122-200).
-
-    Returns (closest, total_slots, steps).  Each step: frame index ``ti``, number of leading bank
-    slots the reader sees (``n_read``), the slot the frame's own key/value are written to afterwards
-    (``None`` for the last frame of the pass) and whether the frame is fused.  Every propagated frame is
-    written to the slot at the front (a temporary 'previous frame' memory); the front only advances
-    — i.e. the frame is kept — when it is at least ``mem_freq`` frames from the last kept one."""
-    if forward:
-        closest = min([x for x in interacted if x > idx] + [t])
-        frames = list(range(idx + 1, closest))
-    else:
-        closest = max([x for x in interacted if x < idx] + [-1])
-        frames = list(range(idx - 1, closest, -1))
+def plan_frames(frames, idx, mem_freq, n_certain, fuse=False):
+    """Memory schedule of a run of frames propagated from frame idx (reference do_pass, inference_core.py:165-198;
+    generation/fusion_generator.py:58-78).  Returns (total_slots, steps).  Each step: frame index ``ti``, number of leading bank
+    slots the reader sees (``n_read``), the slot the frame's own key/value are written to afterwards (``None`` for the last
+    frame of the run) and whether the frame is fused.  Every propagated frame is written to the slot at the front (a temporary
+    'previous frame' memory); the front only advances - i.e. the frame is kept - when it is at least ``mem_freq`` frames from
+    the last kept one."""
     total = len(frames) // mem_freq + 1 + n_certain
-    fuse = closest != t and closest != -1
     steps, front, last_kept, prev_kept = [], n_certain, idx, True
     for i, ti in enumerate(frames):
         n_read = front if prev_kept else front + 1
@@ -55,6 +47,20 @@ def plan_pass(t, interacted, idx, forward, mem_freq, n_certain):
             if prev_kept:
                 front, last_kept = front + 1, ti
         steps.append(Step(ti, n_read, slot, fuse))
+    return total, steps
+
+
+def plan_pass(t, interacted, idx, forward, mem_freq, n_certain):
+    """Schedule of one propagation pass of InferenceCore (reference: do_pass, inference_core.py:122-200): the frames between idx
+    and the closest interacted frame in that direction (or the end of the clip), fused iff such a frame exists.
+    Returns (closest, total_slots, steps) - see plan_frames."""
+    if forward:
+        closest = min([x for x in interacted if x > idx] + [t])
+        frames = list(range(idx + 1, closest))
+    else:
+        closest = max([x for x in interacted if x < idx] + [-1])
+        frames = list(range(idx - 1, closest, -1))
+    total, steps = plan_frames(frames, idx, mem_freq, n_certain, fuse=closest != t and closest != -1)
     return closest, total, steps
 
 

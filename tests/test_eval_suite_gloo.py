@@ -84,3 +84,38 @@ def test_two_rank_gloo_suite(tmp_path):
                           "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
                          capture_output=True, text=True, env=env, timeout=240)
     assert "SUITE_OK 23" in out.stdout, out.stdout + out.stderr
+
+
+def test_generator_suite_with_a_stub_generator():
+    """run_generator_suite (generate_fusion.py:68-120 over a sharded suite): reference frames every `separation`, usable-object
+    filter (> 100 pixels, at most 5), two-sided propagation over the whole clip; both ranks' shares together = the single run."""
+    import numpy as np
+
+    class StubGen:
+        def __init__(self, spec):
+            self.spec, self.calls = spec, []
+        def reset(self, k):
+            self.k = k
+        def interact_mask(self, mask, idx, left, right):
+            self.calls.append((idx, left, right, self.k))
+            return np.full((self.k + 1, self.spec.frames, 6, 8), idx / 255.0, dtype=np.float32)
+
+    gens = {}
+    def factory(spec):
+        gt = np.zeros((spec.frames, spec.objects, 1, 20, 20), dtype=np.float32)
+        gt[:, 0] = 1.0                                     # object 0 fills the frame, the others are empty (not usable)
+        if spec.objects > 1:
+            gt[:, 1, :, :5, :5] = 1.0                      # 25 pixels: below the 10 x 10 threshold
+        gens[spec.clip_id] = StubGen(spec)
+        return gens[spec.clip_id], gt
+
+    specs = ES.synthetic_suite(7)
+    recs = ES.run_generator_suite(specs, factory, separation=5)
+    assert sorted(r["clip"] for r in recs) == list(range(7))
+    for r in recs:
+        s = specs[r["clip"]]
+        n_ref = len(range(0, s.frames, 5))
+        assert r["reference_frames"] == n_ref and r["frames"] == n_ref * (s.frames - 1)
+        assert gens[s.clip_id].calls == [(f, 0, s.frames - 1, 1) for f in range(0, s.frames, 5)]
+    two = ES.run_generator_suite(specs, factory, 0, 2) + ES.run_generator_suite(specs, factory, 1, 2)
+    assert ES.summarize(two, 7)["checksum"] == ES.summarize(recs, 7)["checksum"]

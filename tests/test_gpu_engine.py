@@ -240,6 +240,33 @@ def test_fusion_generator_call_pattern_vs_oracle(nets, synthetic_states):
                 prev = None
 
 
+def test_fusion_generator_golden(nets, golden_dir, synthetic_states):
+    """The engine's FusionGenerator (reference generation/fusion_generator.py:12-101) on the clip of tests/golden/gen_small.npz - two
+    reference frames, the second with range limits inside the clip, the query cache shared between them - against the unmodified
+    reference's probabilities (fp32), arbitrated by an fp64 run of the oracle's restatement."""
+    from mivos_amd.generation.fusion_generator import FusionGenerator
+    prop, _ = nets
+    with np.load(os.path.join(golden_dir, "gen_small.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    c = json.loads(str(g["config"]))
+    images, gt = O.synthetic_clip(c["t"], c["h"], c["w"], c["k"], c["seed"])
+    gen = FusionGenerator(prop, images.to(DEV), c["mem_freq"])
+    g64 = O.OracleGenerator(synthetic_states[0], images, c["mem_freq"], top_k=c["top_k"], dtype=torch.float64)
+    for n, (idx, left, right) in enumerate(c["calls"]):
+        gen.reset(c["k"])
+        g64.reset(c["k"])
+        out = gen.interact_mask(gt[idx, 1:].to(DEV), idx, left, right)
+        r64 = g64.interact_mask(gt[idx, 1:], idx, left, right)
+        ref = T(g[f"prob_{n}"])
+        assert out.shape == ref.shape == (c["k"] + 1, c["t"], c["h"], c["w"])
+        assert mean_iou(out.argmax(0).cpu().numpy(), ref.argmax(0).numpy(), c["k"]) >= 0.999
+        ok, rec = fp64_gate(f"fusion_generator[{n}]", out.unsqueeze(2), ref.unsqueeze(2), r64.unsqueeze(2))
+        assert ok, rec
+        if left > 0:
+            assert float(out[:, :left].abs().max()) == 0.0                   # frames outside the range keep reset()'s zeros
+    assert gen.propagated_frames == 5 + 4 and len(gen.query_buf) == 6        # 6 frames encoded ONCE for both reference frames
+
+
 def test_end_to_end_golden(nets, golden_dir, synthetic_states):
     """Same 3-interaction session (incl. fusion) the unmodified reference ran to produce e2e_small.npz."""
     prop, fuse = nets
