@@ -209,6 +209,15 @@ int mivos_memory_read_dense(const float *keys, int64_t keys_ostride, const float
                             int64_t a_rstride, int64_t a_pstride, int q_width, int n_obj, int64_t n_mem, int n_q, void *workspace,
                             int64_t workspace_bytes, void *stream);
 
+/* Top-k read for ANY k up to 1024 (prop_net.py:133 accepts every top_k; the streaming kernels above hold k <= 64): per chunk of
+ * queries the affinity rows go to `workspace` (exact fp32 MFMA), then one workgroup per (object, query) finds the exact k-th largest
+ * by a radix select, takes the k survivors (ties: lowest memory positions), softmax (prop_net.py:54-59) and readout.  out rows like
+ * mivos_memory_read_topk (may be NULL); idx_out / weight_out [n_obj][n_q][k] optional (survivors in list order, not ranked). */
+int64_t mivos_memory_read_topk_any_workspace_bytes(int n_obj, int64_t n_mem, int n_q);
+int mivos_memory_read_topk_any(const float *keys, int64_t keys_ostride, const float *values, int64_t values_ostride, const float *qk,
+                               float *out, int64_t out_ostride, int64_t out_pstride, int32_t *idx_out, float *weight_out, int n_obj,
+                               int64_t n_mem, int n_q, int top_k, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* --------------------------------------------------------------------------------------------
  * FusionNet training step (model/fusion_model.py:54-131 FusionModel.do_pass; model/losses.py:21-76; train.py:96-124).
  * The forward pass and the data gradients are mivos_conv2d_fused / mivos_fusion_* launches (dgrad of a 3x3 convolution =
@@ -247,7 +256,8 @@ int mivos_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
  *                                   1/sqrt(128) exactly like prop_net.py:86)
  *   out    [n_obj][n_q] rows of 512 floats at out + o*out_ostride + q*out_pstride
  * workspace: mivos_memory_read_workspace_bytes() bytes of device scratch (the per-segment candidate lists).
- * Returns MIVOS_ERR_TOPK_RANGE when top_k > n_mem (reference raises).  top_k <= 64.
+ * Returns MIVOS_ERR_TOPK_RANGE when top_k > n_mem (reference raises).  top_k <= 64 (larger k: mivos_memory_read_topk_any;
+ * no top-k at all: mivos_memory_read_dense).
  * The read is two launches, also callable one by one (profilers time the affinity/selection kernel alone):
  *   mivos_memory_read_select   - persistent affinity + streaming top-k kernel, candidate lists -> workspace
  *   mivos_memory_read_finalize - exact merge, softmax over the k survivors, value gather -> out
@@ -370,6 +380,14 @@ typedef struct mivos_interleave_desc_s {
   int32_t C;
 } mivos_interleave_desc;
 int mivos_interleave_planes(const mivos_interleave_desc *d, float *out, int N, int64_t P, void *stream);
+
+/* ResNet stem of the encoders (modules.py:54-58 / 81-83: cat([frame, mask, others]) -> conv1 7x7 / 2 / pad 3 -> bn1 -> relu) in
+ * one launch from the PLANAR inputs: channel c of image n = planes->plane[c] + n * planes->nstride[c] (n_planes <= 8, all non-NULL),
+ * w_ohwi = fp32 weights [64][7][7][cin] (cin >= n_planes, <= 8; extra input channels have zero weights), the f16x3 arithmetic of
+ * mivos_conv2d_fused precision 1 (weights pre-scaled by the power of two `mult`, scale[c] includes 1 / mult and the BN factor),
+ * y [N][Ho][Wo][64] fp32 = relu(conv * scale + bias), Ho = (H - 1) / 2 + 1. */
+int mivos_stem7x7s2_planes(const mivos_interleave_desc *planes, int n_planes, const float *w_ohwi, int cin, float mult,
+                           const float *scale, const float *bias, float *y, int N, int H, int W, void *stream);
 
 /* ---- scribble-to-mask network (model/s2m: DeepLabV3+ / ResNet-50, the step before the path, davis_processor.py:38-70) ----
  * Its convolutions run on mivos_conv2d_fused (dilation field); these are the remaining operators. */

@@ -53,6 +53,7 @@ PROTOTYPES = {
     "mivos_fusion_net_forward": (C.c_int, [C.POINTER(FusionNetDesc), vp]),
     "mivos_fusion_resblock": (C.c_int, [vp, vp, C.POINTER(FusionLayer), C.POINTER(FusionLayer), C.c_int, C.c_int, C.c_int, vp]),
     "mivos_fusion_head": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "mivos_stem7x7s2_planes": (C.c_int, [C.POINTER(InterleaveDesc), C.c_int, vp, C.c_int, C.c_float, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_fusion_conv1_planes": (C.c_int, [C.POINTER(InterleaveDesc), C.POINTER(FusionLayer), vp, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_fusion_wgrad_scratch_floats": (i64, []),
     "mivos_fusion_wgrad3x3": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, vp]),
@@ -79,6 +80,8 @@ PROTOTYPES = {
     "mivos_memory_read_set_q128_min": (i64, [i64]),
     "mivos_memory_read_dense_workspace_bytes": (i64, [C.c_int, i64, C.c_int]),
     "mivos_memory_read_dense": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, i64, i64, i64, C.c_int, C.c_int, i64, C.c_int, vp, i64, vp]),
+    "mivos_memory_read_topk_any_workspace_bytes": (i64, [C.c_int, i64, C.c_int]),
+    "mivos_memory_read_topk_any": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
     "mivos_memory_read_plan": (C.c_int, [C.c_int, i64, C.c_int, C.c_int, C.c_int, C.POINTER(i32)]),
     "mivos_memory_read_select": (C.c_int, [vp, i64, vp, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),
     "mivos_memory_read_finalize": (C.c_int, [vp, i64, vp, i64, i64, C.c_int, i64, C.c_int, C.c_int, vp, i64, vp]),

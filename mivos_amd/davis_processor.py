@@ -43,10 +43,11 @@ class DAVISProcessor:
             rs, _ = pad_divide_by(rs, 16, rs.shape[-2:])                         # padded AFTER the dilation, like the reference
             frame = self.processor.get_image_buffered(idx)                       # [1,3,nh,nw]
             cur = self.processor.masks[idx].to(self.device)                      # [1,nh,nw] uint8
-            mask = torch.empty((K, 1, self.nh, self.nw), dtype=torch.float32, device=self.device)
-            for ki in range(1, K + 1):
-                inputs = torch.cat([frame, (cur == ki).float().unsqueeze(0), rs[0, ki - 1][None, None], rs[1, ki - 1][None, None]], 1)
-                mask[ki - 1] = ops.sigmoid(self.s2m_net(inputs))[0]              # hard mask input: S2M is trained with such
+            # one S2M forward for all K objects (the reference calls the network once per object, davis_processor.py:62-68): sample
+            # ki = cat([frame, current mask of object ki (hard: S2M is trained with such), its positive / negative scribbles])
+            cur_k = (cur[None] == ids.view(K, 1, 1, 1)).float()                      # [K,1,nh,nw]
+            inputs = torch.cat([frame.expand(K, -1, -1, -1), cur_k, rs[0].unsqueeze(1), rs[1].unsqueeze(1)], 1)
+            mask = ops.sigmoid(self.s2m_net(inputs))
             return aggregate_wbg(mask, keep_bg=True, hard=True)
 
     def to_mask(self, scribble):

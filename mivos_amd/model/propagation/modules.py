@@ -16,6 +16,11 @@ from ... import ops
 from ...ops import ConvLayer
 
 
+import os
+
+STEM_FROM_PLANES = os.environ.get("MIVOS_STEM_PLANES", "1") != "0"     # tuning / A-B only: 0 = interleave + implicit-GEMM stem
+
+
 class ConvParams(nn.Module):
     """Holds `weight` (+ `bias`) of an nn.Conv2d; no torch forward."""
 
@@ -111,12 +116,22 @@ class _Trunk(nn.Module):
         return (self.conv1.pack(self.bn1, cin_pad=cin_pad), stages)
 
 
-def run_trunk(plan, x, keep=True):
+def run_trunk_planes(plan, planes, n, H, W, keep=True):
+    """run_trunk on PLANAR input channels [(tensor, batch_stride), ...] (the frame's three planes, plus mask / others for the
+    mask encoder: modules.py:54 cat([f, m, o])): with the f16x3 back-end the stem gathers them itself (mivos_stem7x7s2_planes),
+    otherwise they are interleaved into the NHWC tensor run_trunk takes."""
+    stem, stages = plan
+    if ops.act_path() and STEM_FROM_PLANES:
+        return run_trunk(plan, None, keep, stem_out=ops.stem_planes(planes, n, H, W, stem))
+    return run_trunk(plan, ops.interleave(planes, n, H * W, stem.cin, stem.w.device).view(n, H, W, stem.cin), keep)
+
+
+def run_trunk(plan, x, keep=True, stem_out=None):
     """x NHWC [N,H,W,4|8] -> (f16, f8, f4).  With the f16x3 back-end everything behind the stem runs on the LDS-DMA
     kernels and the features are ops.Act (SH32, zero-bordered); keep=False puts them into scratch storage too (the
-    caller consumes them before the next trunk call)."""
+    caller consumes them before the next trunk call).  stem_out: the stem's output when the caller ran it already."""
     stem, stages = plan
-    x = ops.conv(x, stem, relu_out=True)
+    x = stem_out if stem_out is not None else ops.conv(x, stem, relu_out=True)
     x = ops.maxpool3x3s2(x, act_tag="trunk.stem", as_act=True) if ops.act_path() else ops.maxpool3x3s2(x)   # SH32 from the pool itself
     feats = []
     for stage in stages:

@@ -19,7 +19,7 @@ from ... import ops
 from ..._lib import MivosHipError
 from ..plan_cache import PlanCache
 from .modules import (ConvParams, KeyValue, MaskRGBEncoder, ResBlock, RGBEncoder, UpsampleBlock,
-                      run_resblock, run_resblock_acts, run_skip_branch, run_trunk, run_up_branch)
+                      run_resblock, run_resblock_acts, run_skip_branch, run_trunk_planes, run_up_branch)
 
 CK, CV = 128, 512
 
@@ -103,16 +103,17 @@ def _nhwc(t):
     return x if x.is_contiguous() else x.contiguous()
 
 
-MAX_TOP_K = 64      # csrc/memory_read.hip: candidate lists are sized for k <= 64 (the reference default is 50, the
-                    # DAVIS single-object configuration uses 20)
+MAX_TOP_K = 1024    # k <= 64 (the reference default is 50, the DAVIS single-object configuration uses 20) runs on the streaming
+                    # select kernels of csrc/memory_read.hip, 64 < k <= 1024 on the scores + radix-select path of
+                    # csrc/memory_read_dense.hip (ablations), top_k=None on the full-softmax kernel
 
 
 class PropagationNetwork(PlanCache):
     def __init__(self, top_k=50):
         super().__init__()
         if top_k is not None and not (1 <= int(top_k) <= MAX_TOP_K):
-            raise MivosHipError(f"PropagationNetwork(top_k={top_k}): the MI355X top-k memory-read kernels support 1 <= top_k <= "
-                                f"{MAX_TOP_K} (reference default 50), or top_k=None = softmax over the whole bank (prop_net.py:99-102)")
+            raise MivosHipError(f"PropagationNetwork(top_k={top_k}): the MI355X memory-read kernels support 1 <= top_k <= {MAX_TOP_K} "
+                                f"(reference default 50), or top_k=None = softmax over the whole bank (prop_net.py:99-102)")
         self.mask_rgb_encoder = MaskRGBEncoder()
         self.rgb_encoder = RGBEncoder()
         self.kv_m_f16 = KeyValue(1024, keydim=CK, valdim=CV)
@@ -141,8 +142,7 @@ class PropagationNetwork(PlanCache):
         p = self.plan()
         _, _, H, W = frame.shape
         frame = frame.contiguous()
-        x = ops.interleave([(frame[0, c], 0) for c in range(3)], 1, H * W, 4, frame.device).view(1, H, W, 4)
-        f16, f8, f4 = run_trunk(p["qenc"], x)
+        f16, f8, f4 = run_trunk_planes(p["qenc"], [(frame[0, c], 0) for c in range(3)], 1, H, W)
         k16, v16 = ops.conv(f16, p["kv_q"])
         return QueryFeatures(f16, f8, f4, k16, v16)
 
@@ -160,8 +160,7 @@ class PropagationNetwork(PlanCache):
         frames = frames.contiguous()
         P = H * W
         flat = frames.reshape(-1)
-        x = ops.interleave([(flat[c * P:], 3 * P) for c in range(3)], B, P, 4, frames.device).view(B, H, W, 4)
-        f16, f8, f4 = run_trunk(p["qenc"], x)
+        f16, f8, f4 = run_trunk_planes(p["qenc"], [(flat[c * P:], 3 * P) for c in range(3)], B, H, W)
         k16, v16 = ops.conv(f16, p["kv_q"])
         s8 = s4 = c1v = dsv = None
         if with_skip:
@@ -216,8 +215,7 @@ class PropagationNetwork(PlanCache):
         K, _, H, W = masks.shape
         P = H * W
         planes = [(frame[0, c], 0) for c in range(3)] + [(masks, P), (others, P)]
-        x = ops.interleave(planes, K, P, 8, frame.device).view(K, H, W, 8)
-        f16, _, _ = run_trunk(p["menc"], x, keep=False)
+        f16, _, _ = run_trunk_planes(p["menc"], planes, K, H, W, keep=False)
         return ops.conv(f16, p["kv_m"], out=key_out, out2=val_out)
 
     def segment(self, keys, values, q, logits=False, keys_split=None):

@@ -82,7 +82,8 @@ class S2M(PlanCache):
                 aspp = [c.aspp.convs[i][0].pack(c.aspp.convs[i][1]) for i in range(4)]
                 pool = c.aspp.convs[4][1].pack(c.aspp.convs[4][2])
                 proj = c.aspp.project[0].pack(c.aspp.project[1])                     # 1x1, 1280 -> 256, BN folded into scale / bias
-                proj_main = ops.ConvLayer(proj.w[..., :1024].contiguous(), proj.scale, proj.bias, 1, 0)
+                # the projection over the four spatial branches: its BN shift travels with the pooling branch's term (proj_pool)
+                proj_main = ops.ConvLayer(proj.w[..., :1024].contiguous(), proj.scale, None, 1, 0)
                 proj_pool = ops.ConvLayer(proj.w[..., 1024:].contiguous(), proj.scale, proj.bias, 1, 0)
                 # low-level projection: 48 output channels padded to 64 (zero rows, zero shift: relu(0) = 0)
                 lp = c.project[0].pack(c.project[1])
@@ -93,7 +94,7 @@ class S2M(PlanCache):
                 w = cl.w.new_zeros((256, 3, 3, 320))
                 w[..., :48], w[..., 64:] = cl.w[..., :48], cl.w[..., 48:]
                 cls0 = ops.ConvLayer(w, cl.scale, cl.bias, 1, 1)
-                self._plan = dict(stem=b.conv1.pack(b.bn1, cin_pad=8), stages=stages, aspp=aspp, pool=pool, proj_main=proj_main,
+                self._plan = dict(stem=b.conv1.pack(b.bn1, cin_pad=8), stages=stages, aspp=aspp, pool=pool, proj_main_nobias=proj_main,
                                   proj_pool=proj_pool, low=low, cls0=cls0, cls1=c.classifier[3].pack())
                 self._stamp_plan()
         return self._plan
@@ -106,13 +107,18 @@ class S2M(PlanCache):
         with ops.on_device(x), torch.no_grad():
             p = self.plan()
             x = x.contiguous().float()
-            outs = [self._forward_one(p, x[n:n + 1], H, W) for n in range(N)]     # the image-pooling bias is per image
-            return outs[0] if N == 1 else torch.cat(outs, 0)
+            cap = ops.max_act_batch(H // 4, W // 4, 256)                                # 32-bit offsets of the LDS-DMA kernels
+            if N > cap:
+                return torch.cat([self._forward_batch(p, x[n:n + cap], H, W) for n in range(0, N, cap)], 0)
+            return self._forward_batch(p, x, H, W)
 
-    def _forward_one(self, p, x, H, W):
-        P = H * W
+    def _forward_batch(self, p, x, H, W):
+        """All N samples in one chain of launches (DAVISProcessor hands over one sample per object of the interaction,
+        davis_processor.py:52-70).  The image-pooling branch of ASPP is constant over an image: its share of the 1x1 projection
+        enters that convolution as a per-image vector, passed as a residual whose row / pixel strides are zero."""
+        N, P = x.shape[0], H * W
         flat = x.reshape(-1)
-        xin = ops.interleave([(flat[c * P:], 0) for c in range(6)], 1, P, 8, x.device).view(1, H, W, 8)
+        xin = ops.interleave([(flat[c * P:], 6 * P) for c in range(6)], N, P, 8, x.device).view(N, H, W, 8)
         y = ops.conv(xin, p["stem"], relu_out=True)
         act = ops.act_path()
         y = ops.maxpool3x3s2(y, act_tag="s2m.stem", as_act=True) if act else ops.maxpool3x3s2(y)
@@ -126,18 +132,18 @@ class S2M(PlanCache):
             if si == 0:
                 low_level = y
         h, w = H // 16, W // 16
-        cat = torch.empty((1, h, w, 1024), dtype=torch.float32, device=x.device)
+        cat = torch.empty((N, h, w, 1024), dtype=torch.float32, device=x.device)
         for i, L in enumerate(p["aspp"]):
             ops.conv(y, L, relu_out=True, out=cat[..., 256 * i:256 * (i + 1)])
-        pooled = ops.conv(ops.global_avgpool(y), p["pool"], relu_out=True)             # [1,1,1,256], constant over the image
-        pool_bias = ops.conv(pooled, p["proj_pool"]).view(256)                          # scale * (W_pool . pooled) + BN shift
-        aspp_out = ops.conv(cat, p["proj_main"], relu_out=True, bias=pool_bias)         # Dropout(0.1) is the identity in eval
-        cat2 = torch.zeros((1, H // 4, W // 4, 320), dtype=torch.float32, device=x.device)
+        pooled = ops.conv(ops.global_avgpool(y), p["pool"], relu_out=True)             # [N,1,1,256], constant over each image
+        pool_term = ops.conv(pooled, p["proj_pool"])                                    # scale * (W_pool . pooled) + BN shift, [N,1,1,256]
+        aspp_out = ops.conv(cat, p["proj_main_nobias"], relu_out=True, res=pool_term.expand(N, h, w, 256))   # Dropout(0.1): identity in eval
+        cat2 = torch.zeros((N, H // 4, W // 4, 320), dtype=torch.float32, device=x.device)
         ops.conv(low_level, p["low"], relu_out=True, out=cat2[..., :64])
         ops.resize_bilinear_nhwc(aspp_out, H // 4, W // 4, out=cat2[..., 64:])
         z = ops.conv(ops.to_act(cat2, tag="s2m.cat"), p["cls0"], relu_out=True) if act else self._cls0_f32(p, cat2)
-        lo = ops.conv(z, p["cls1"])                                                     # [1,H/4,W/4,1]
-        return ops.resize_bilinear(lo.view(1, H // 4, W // 4), H, W).view(1, 1, H, W)
+        lo = ops.conv(z, p["cls1"])                                                     # [N,H/4,W/4,1]
+        return ops.resize_bilinear(lo.view(N, H // 4, W // 4), H, W).view(N, 1, H, W)
 
     @staticmethod
     def _cls0_f32(p, cat2):

@@ -77,7 +77,7 @@ def _nhwc_strides(t):
 
 class ConvLayer:
     """Device-resident packed convolution: OHWI weights (+ folded BN scale / bias)."""
-    __slots__ = ("w", "scale", "bias", "cin", "cout", "k", "stride", "pad", "split", "w16", "scale16", "wdma", "proj", "dil")
+    __slots__ = ("w", "scale", "bias", "cin", "cout", "k", "stride", "pad", "split", "w16", "scale16", "wdma", "proj", "dil", "mult16")
 
     def __init__(self, w_ohwi, scale, bias, stride, pad, split=None, dil=1):
         self.w = w_ohwi.contiguous()
@@ -85,7 +85,7 @@ class ConvLayer:
         self.scale, self.bias = scale, bias
         self.stride, self.pad, self.dil = stride, pad, dil
         self.split = self.cout if split is None else split
-        self.w16 = self.scale16 = self.wdma = self.proj = None
+        self.w16 = self.scale16 = self.wdma = self.proj = self.mult16 = None
 
     def projection(self):
         """A 3x3 / pad 1 layer with ONE output channel as a 1x1 layer with 16 outputs, row k = the weights of tap k
@@ -111,6 +111,15 @@ class ConvLayer:
         mult = 2.0 ** s
         base = self.scale if self.scale is not None else torch.ones(self.cout, dtype=torch.float32, device=self.w.device)
         return mult, (base * (1.0 / mult)).contiguous()
+
+    def split_scale(self):
+        """(2^s, epilogue scale incl. 2^-s) of the fp16 hi/lo weight split, computed once (kernels that split the fp32 weights
+        themselves: mivos_stem7x7s2_planes)."""
+        if self.mult16 is None:
+            self.mult16, sc = self._f16x3_scale()
+            if self.scale16 is None:
+                self.scale16 = sc
+        return self.mult16, self.scale16
 
     def dma(self):
         """(weights packed for the LDS-DMA kernels (precision 2), epilogue scale); needs cin % 32 == 0."""
@@ -169,7 +178,7 @@ class ConvLayer:
             v = getattr(self, n)
             if v is not None:
                 setattr(self, n, v.to(device))
-        self.w16 = self.scale16 = self.wdma = self.proj = None
+        self.w16 = self.scale16 = self.wdma = self.proj = self.mult16 = None
         return self
 
 
@@ -440,6 +449,18 @@ def fusion_head(x, final):
     return out
 
 
+def stem_planes(planes, n, H, W, L):
+    """ResNet stem (7x7 / 2 / pad 3 conv + folded BN + ReLU, 64 channels) straight from planar inputs (mivos_stem7x7s2_planes):
+    planes = [(tensor, batch_stride)] (<= 8, no constants), L = the packed stem ConvLayer -> fp32 [n, H/2, W/2, 64]."""
+    assert (L.k, L.stride, L.pad, L.cout, L.dil) == (7, 2, 3, 64, 1) and len(planes) <= L.cin <= 8 and CONV_PRECISION == "f16x3"
+    d, keep = _interleave_desc(planes, 8)
+    mult, scale16 = L.split_scale()
+    out = torch.empty((n, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), dtype=torch.float32, device=L.w.device)
+    check(_lib.load().mivos_stem7x7s2_planes(C.byref(d), len(planes), L.w.data_ptr(), L.cin, mult, scale16.data_ptr(),
+                                              L.bias.data_ptr() if L.bias is not None else None, out.data_ptr(), n, H, W, _stream()))
+    return out
+
+
 # ---- FusionNet training step (csrc/fusion_train.hip; reference model/fusion_model.py:54-131, model/losses.py) -----------------
 
 def fusion_wgrad3x3(x, g):
@@ -591,6 +612,9 @@ def split_keys(keys, out=None):
     return out
 
 
+STREAMING_MAX_TOP_K = 64     # csrc/memory_read.hip: candidate lists of the streaming select kernels
+
+
 def _memread_select(lib, keys, ko, keys_split, qk, k, n_mem, n_q, top_k, ws):
     """The affinity + streaming top-k launch in the engine's precision: "f16x3" streams pre-split keys (the caller's split
     bank, or a conversion of `keys` into scratch when there is none), "f32" the fp32 rows through the exact fp32 MFMA kernel."""
@@ -640,6 +664,11 @@ def memory_read(keys, values, qk, top_k, out=None, keys_split=None):
         check(lib.mivos_memory_read_dense(keys.data_ptr(), ko, values.data_ptr(), vo, qk.data_ptr(), out.data_ptr(), out.stride(0), out.stride(1),
                                           None, None, 0, 0, 0, 1, k, n_mem, n_q, ws.data_ptr(), ws.numel(), _stream()))
         return out
+    if top_k > STREAMING_MAX_TOP_K:     # beyond the streaming kernels' candidate lists: scores to scratch + radix select per query
+        ws = _workspace(lib.mivos_memory_read_topk_any_workspace_bytes(k, n_mem, n_q), keys.device, "memread_any")
+        check(lib.mivos_memory_read_topk_any(keys.data_ptr(), ko, values.data_ptr(), vo, qk.data_ptr(), out.data_ptr(), out.stride(0), out.stride(1),
+                                             None, None, k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
+        return out
     ws = _workspace(lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k), keys.device, "memread")
     ev = None
     if PROFILE is not None:      # bench.py: HIP events on the launch stream around each of the two launches
@@ -671,6 +700,9 @@ def memory_read_acts(keys, values, qk, top_k, h, w, tag="memread", keys_split=No
         check(lib.mivos_memory_read_dense(keys.data_ptr(), ko, values.data_ptr(), vo, qk.data_ptr(), None, 0, 0, raw.interior_ptr(), rel.interior_ptr(),
                                           an, ar, ap, w, k, n_mem, n_q, ws.data_ptr(), ws.numel(), _stream()))
         return raw, rel
+    if top_k > STREAMING_MAX_TOP_K:
+        dense = memory_read(keys, values, qk, top_k).view(k, h, w, 512)
+        return to_act(dense, out=raw), to_act(dense, relu=True, out=rel)
     ws = _workspace(lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k), keys.device, "memread")
     ev = None
     if PROFILE is not None:
@@ -696,6 +728,11 @@ def memory_read_indices(keys, qk, top_k, keys_split=None):
     idx = torch.empty((k, n_q, top_k), dtype=torch.int32, device=keys.device)
     wgt = torch.empty((k, n_q, top_k), dtype=torch.float32, device=keys.device)
     lib = _lib.load()
+    if top_k > STREAMING_MAX_TOP_K:     # (survivors in list order, not ranked)
+        ws = _workspace(lib.mivos_memory_read_topk_any_workspace_bytes(k, n_mem, n_q), keys.device, "memread_any")
+        check(lib.mivos_memory_read_topk_any(keys.data_ptr(), ko, None, 0, qk.data_ptr(), None, 0, 0, idx.data_ptr(), wgt.data_ptr(), k, n_mem, n_q,
+                                             top_k, ws.data_ptr(), ws.numel(), _stream()))
+        return idx, wgt
     ws = _workspace(lib.mivos_memory_read_workspace_bytes(k, n_mem, n_q, top_k), keys.device, "memread")
     _memread_select(lib, keys, ko, keys_split, qk, k, n_mem, n_q, top_k, ws)
     check(lib.mivos_memory_read_finalize_indices(idx.data_ptr(), wgt.data_ptr(), k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))

@@ -344,6 +344,41 @@ def test_fusion_head_exact_fp32(B, H, W):
     assert rel_err(nb.cpu().permute(0, 3, 1, 2), ref - b.double()) < 1e-6
 
 
+@pytest.mark.parametrize("N,n_planes,cin,H,W", [(1, 3, 4, 64, 96), (2, 5, 8, 50, 70), (5, 5, 8, 480, 864), (8, 3, 4, 128, 160), (1, 5, 8, 17, 33)])
+def test_stem_from_planes(N, n_planes, cin, H, W):
+    """mivos_stem7x7s2_planes (7x7 / 2 / pad 3 conv + BN + ReLU straight from planar inputs: the stems of the query encoder - 3
+    planes, Cin padded to 4 - and of the mask encoder - frame planes shared by all objects + per-object mask / others planes) vs
+    the interleave + implicit-GEMM path it replaces and vs fp64 torch; even, odd and tiny sizes (tiles cut by the image edge)."""
+    g = torch.Generator().manual_seed(N * 100 + H)
+    P = H * W
+    frame = torch.randn(3, H, W, generator=g).to(DEV)
+    extra = torch.rand(N, max(n_planes - 3, 1), H, W, generator=g).to(DEV)
+    w = torch.randn(64, n_planes, 7, 7, generator=g) * (2.0 / (49 * n_planes)) ** 0.5
+    bn = (torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5)
+    L = ConvLayer.pack(w, None, bn, 2, 3, cin_pad=cin).to(DEV)
+    if n_planes == 3:
+        batch = torch.randn(N, 3, H, W, generator=g).to(DEV)                      # N different frames (query batches)
+        flat = batch.reshape(-1)
+        planes = [(flat[c * P:], 3 * P) for c in range(3)]
+        x = batch.cpu()
+    else:
+        ef = extra.reshape(-1)
+        planes = [(frame[c], 0) for c in range(3)] + [(ef[j * P:], (n_planes - 3) * P) for j in range(n_planes - 3)]
+        x = torch.cat([frame.cpu().expand(N, -1, -1, -1), extra.cpu()], 1)
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f16x3"
+    try:
+        got = ops.stem_planes(planes, N, H, W, L)
+        ref = ops.conv(ops.interleave(planes, N, P, cin, frame.device).view(N, H, W, cin), L, relu_out=True)
+    finally:
+        ops.CONV_PRECISION = old
+    s = (bn[0] / torch.sqrt(bn[3] + 1e-5)).double()
+    ref64 = F.relu(F.conv2d(x.double(), w.double(), None, stride=2, padding=3) * s[None, :, None, None] + (bn[1].double() - bn[2].double() * s)[None, :, None, None])
+    assert got.shape == ref.shape == (N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64)
+    e, r = rel_err(got.cpu().permute(0, 3, 1, 2), ref64), rel_err(ref.cpu().permute(0, 3, 1, 2), ref64)
+    print(f"stem [{N}x{n_planes}x{H}x{W}]: vs fp64 {e:.2e} (implicit-GEMM path: {r:.2e}), vs that path {float((got - ref).abs().max()):.2e}")
+    assert e < 3e-6 and float((got - ref).abs().max()) < 2e-5 * float(ref64.abs().max())
+
+
 def test_maxpool_and_upsample_add():
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 64, 37, 45, generator=g)
@@ -543,6 +578,23 @@ def test_memory_read_full_softmax_vs_oracle(T, h, w, K):
     m4 = torch.full((K, h * w, 1024), 7.0, device=DEV)
     ops.memory_read(keys, vals, q, None, out=m4[:, :, :512])                     # channel-slice destination
     assert torch.equal(m4[:, :, :512], got) and float((m4[:, :, 512:] - 7).abs().max()) == 0
+
+
+@pytest.mark.parametrize("T,h,w,K,top_k", [(3, 9, 13, 2, 65), (5, 30, 54, 2, 128), (2, 30, 54, 1, 1000), (1, 8, 10, 1, 80)])
+def test_memory_read_large_k_vs_oracle(T, h, w, K, top_k):
+    """k beyond the streaming kernels (64 < k <= 1024; top_k == THW too): scores + radix-select path (mivos_memory_read_topk_any) vs
+    the oracle - exact index sets on clear-margin queries, readout, weights summing to one."""
+    mk, mv, qk = _mem_case(T, h, w, K, seed=T * 1000 + top_k, scale=1.3)
+    got, idx, wgt = _run_mem(mk, mv, qk, top_k)
+    for o in range(K):
+        ref = O.memory_read(mk[o:o + 1].double(), mv[o:o + 1].double(), qk.double(), top_k)
+        a = O.affinity(mk[o:o + 1].double(), qk.double())[0]
+        vals, ridx = torch.topk(a, min(top_k + 1, a.shape[0]), dim=0)
+        clear = (vals[top_k - 1] - vals[top_k]) > 1e-5 if a.shape[0] > top_k else torch.ones(a.shape[1], dtype=torch.bool)
+        d = (got[o].double() - ref[0]).abs().amax(0).reshape(-1)
+        assert float(d[clear].max()) < 2e-4 and int((~clear).sum()) <= max(2, clear.numel() // 50)
+        same = (torch.sort(idx[o].long(), dim=1)[0] == torch.sort(ridx[:top_k].t(), dim=1)[0]).all(dim=1)
+        assert bool(same[clear].all()) and float((wgt[o].sum(1) - 1).abs().max()) < 1e-5
 
 
 def test_memory_read_sharp_scores_and_ties(mem_precision):

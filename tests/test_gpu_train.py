@@ -119,7 +119,8 @@ def test_adam_step_vs_torch():
         ops.adam_step(p, grad.to(DEV), m, v, 1e-4, (0.9, 0.999), 1e-8, 1e-7, step)
         assert float((p.cpu() - ref.detach()).abs().max()) < 5e-7              # one ulp of the parameters (|p| up to 8); updates are ~1e-4
     st = opt.state[ref]
-    assert float((m.cpu() - st["exp_avg"]).abs().max()) < 1e-6 and float((v.cpu() - st["exp_avg_sq"]).abs().max()) < 1e-5
+    assert float((m.cpu() - st["exp_avg"]).abs().max()) < 2e-6 * float(st["exp_avg"].abs().max())
+    assert float((v.cpu() - st["exp_avg_sq"]).abs().max()) < 2e-6 * float(st["exp_avg_sq"].abs().max())
 
 
 def _model(para=None, **kw):
