@@ -307,7 +307,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 8 sessions of configs 2/3, the whole clip of config 5)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps before (default: one session of configs 2/3, 8 steps of config 5)")
-    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5))
+    ap.add_argument("--config", type=lambda v: v if v == "s2m" else int(v), default=3, choices=(2, 3, 4, 5, "s2m"),
+                    help="2 / 3 / 4 / 5: BASELINE configs; s2m: the scribble-to-mask step in front of the path (SURVEY 8(f)1)")
     ap.add_argument("--frames", type=int, default=None, help="clip length override (config 5: default 1000)")
     ap.add_argument("--objects", type=int, default=None)
     ap.add_argument("--top-k", type=int, default=None)
@@ -349,6 +350,8 @@ def main():
 
     if args.config == 4:
         return bench_suite(args, torch, ops, shard, rank, world, dev)
+    if args.config == "s2m":
+        return bench_s2m(args, torch, ops, shard, rank, world, dev)
 
     cfg = dict(CONFIGS[args.config])
     for key, val in (("frames", args.frames), ("objects", args.objects), ("top_k", args.top_k)):
@@ -473,7 +476,46 @@ def bench_suite(args, torch, ops, shard, rank, world, dev):
                              f"interact(first frame); clips assigned longest-first to {world} rank(s), no data-path collective; clip generation (GPU) inside the timed region",
                     baseline_config=4, clips=len(specs), parallelism=f"sequence-sharded x{world}", suite_checksum=s["checksum"]),
         roofline=None, cpu_baseline=None, wall_seconds=round(elapsed, 3), busiest_rank_engine_seconds=round(s["busiest_rank_seconds"], 3),
-        per_rank=sorted(per_rank.values(), key=lambda r: r["rank"]))))
+        per_rank=sorted(per_rank.values(), key=lambda r: r["rank"]),
+        # multi-GPU readiness: the measured per-clip cost model (shard.clip_cost assumes frames * (1 + 1.6 * objects)) and the load
+        # imbalance the longest-first assignment of the FULL 474-clip suite would have at 2 / 4 / 8 ranks under either model
+        cost_model=dict(measured=ES.fit_cost_model(allrecs), assumed_per_object_ratio=1.6,
+                        predicted_imbalance_474_clips=dict(assumed=ES.predicted_imbalance(ES.synthetic_suite(474)),
+                                                           measured=(ES.predicted_imbalance(ES.synthetic_suite(474), per_object=ES.fit_cost_model(allrecs)["per_object_ratio"])
+                                                                     if ES.fit_cost_model(allrecs) and ES.fit_cost_model(allrecs)["per_object_ratio"] else None))))))
+
+
+def bench_s2m(args, torch, ops, shard, rank, world, dev):
+    """--config s2m: the scribble-to-mask network of an interaction (davis_processor.py:52-70: one DeepLabV3+ forward per object) at
+    480x854 (padded to 480x864), `--objects` (default 5) objects as ONE batched forward.  step = one interaction's S2M work."""
+    from mivos_amd.model.s2m.s2m_network import deeplabv3plus_resnet50
+    from mivos_amd.util import synthetic
+    K = args.objects or 5
+    net = deeplabv3plus_resnet50()
+    net.load_state_dict(synthetic.make_s2m_state(0))
+    net = net.to(dev).eval()
+    g = torch.Generator().manual_seed(5 + rank)
+    x = torch.randn(K, 6, 480, 864, generator=g).to(dev)
+    x[:, 3:] = (x[:, 3:] > 1.5).float()
+    warmup, steps = args.warmup if args.warmup is not None else 3, args.steps if args.steps is not None else 20
+    for _ in range(warmup):
+        net(x)
+    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = net(x)
+    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
+    if rank != 0:
+        return
+    # 2 * MACs of DeepLabV3+ / ResNet-50 (output stride 16) per 480x864 sample, from the layer shapes (conv hooks on the oracle)
+    print(json.dumps(dict(metric="scribble-to-mask forwards/sec (objects/sec), DAVIS 480p", value=round(world * steps * K / elapsed, 3), unit="objects/s",
+                          n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(elapsed / steps * 1e3, 3), higher_is_better=True, scaling="weak",
+                          vs_baseline=None, dtype="f16x3 convolutions (fp16 hi+lo split operands, 3 fp16 MFMA products per term, fp32 accumulate)",
+                          data="synthetic", config=dict(workload=f"s2m_interaction: DeepLabV3+/ResNet-50 (6 input channels) on {K} x 480x864 samples in one batched "
+                                                                  f"forward = the scribble-to-mask work of one interaction with {K} objects",
+                                                        objects=K, height=480, width=864, parallelism=f"replicas x{world}"),
+                          roofline=None, cpu_baseline=None, logit_range=[round(float(out.min()), 2), round(float(out.max()), 2)])))
 
 
 def bench_generator(args, torch, shard, ES, specs, prop, rank, world, dev):

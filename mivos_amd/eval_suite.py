@@ -111,6 +111,35 @@ def run_generator_suite(specs, generator_factory, rank=0, world=1, separation=5,
     return records
 
 
+def fit_cost_model(records):
+    """Least-squares fit of the measured per-clip seconds to  frames * (a + b * objects)  (the form of shard.clip_cost, whose
+    constant is b / a): returns dict(a_ms, b_ms, per_object_ratio, max_rel_residual)."""
+    A = np.array([[r["frames"], r["frames"] * r["objects"]] for r in records], dtype=np.float64)
+    y = np.array([r["seconds"] for r in records], dtype=np.float64)
+    if len(records) < 2 or len({r["objects"] for r in records}) < 2:
+        return None
+    (a, b), *_ = np.linalg.lstsq(A, y, rcond=None)
+    resid = np.abs(A @ np.array([a, b]) - y) / y
+    return dict(a_ms=round(float(a) * 1e3, 4), b_ms=round(float(b) * 1e3, 4), per_object_ratio=round(float(b / a), 3) if a > 0 else None,
+                max_rel_residual=round(float(resid.max()), 3))
+
+
+def predicted_imbalance(specs, worlds=(2, 4, 8), per_object=None):
+    """Busiest rank's load / mean load of the longest-first assignment, for the cost model frames * (1 + per_object * objects)
+    (per_object=None: shard.clip_cost's constant).  1.0 = perfect balance; the scaling efficiency of a sharded run is at most its
+    inverse."""
+    out = {}
+    for w in worlds:
+        if per_object is None:
+            cost = [shard.clip_cost(s.frames - 1, s.objects) for s in specs]
+        else:
+            cost = [(s.frames - 1) * (1.0 + per_object * s.objects) for s in specs]
+        parts = shard.assign_sequences(cost, w)
+        loads = [sum(cost[i] for i in p) for p in parts]
+        out[str(w)] = round(max(loads) / (sum(loads) / w), 4)
+    return out
+
+
 def summarize(all_records, n_specs=None):
     """Aggregate of the gathered records of all ranks: every clip exactly once, total propagated frames, the busiest
     rank's time (what bounds the wall clock of the sharded run) and the imbalance of the assignment."""

@@ -110,6 +110,11 @@ class InferenceCore:
         self.images, self.pad = pad_divide_by(images, 16, images.shape[-2:])
         self.nh, self.nw = self.images.shape[-2:]
         self.images = self.images.to(self.data_dev)
+        # the default precision carries operands as fp16 hi + lo pairs: inputs beyond the fp16 range would turn into inf / NaN inside
+        # the first convolution (and ReLU would silently turn those into zeros) - refuse them here (one reduction per clip)
+        if ops.CONV_PRECISION == "f16x3" and max(abs(float(v)) for v in self.images.aminmax()) >= 65504.0:
+            raise ops.MivosHipError("InferenceCore: |images| >= 65504 is outside the fp16 range of the f16x3 operands (INTEGRATION.md 'Limits'); "
+                                    "normalise the frames (dataset/range_transform.py) or set ops.CONV_PRECISION = 'f32'")
         self.kh, self.kw = self.nh // 16, self.nw // 16
 
         self.masks = torch.zeros((self.t, 1, self.nh, self.nw), dtype=torch.uint8, device=self.result_dev)
@@ -123,6 +128,7 @@ class InferenceCore:
         self._certain_k = self._certain_v = None     # [K, n, h, w, C] rows per memory position
         self.propagated_frames = 0                   # do_pass iterations so far (the bench metric)
         self._fuse_stream, self._fuse_pending = None, []
+        self._last_propagated = None                 # last frame of the most recent pass (finite-ness probe of _refresh_masks)
 
     # ---- reference-shaped views of the certain memory -------------------------------------
     @property
@@ -249,6 +255,7 @@ class InferenceCore:
             if step_cb is not None:
                 step_cb()
         self._join_fusion()
+        self._last_propagated = steps[-1].ti
         return closest
 
     @_on_core_device
@@ -317,6 +324,20 @@ class InferenceCore:
         frames are uploaded, so the GPU footprint stays O(chunk) like the reference's per-frame loop (:259-260)."""
         l, r, t, b = self.pad
         P = self.nh * self.nw
+        # The f16x3 operands are fp16 hi + lo pairs: an activation or key beyond +-65504 becomes inf and, through the memory bank,
+        # NaN in every later frame.  The last frame of the last pass carries whatever went wrong before it: one tiny reduction,
+        # read back with the masks below.
+        bad = None
+        if self._last_propagated is not None:
+            bad = ~torch.isfinite(self.prob[:, self._last_propagated]).all()
+            self._last_propagated = None
+        masks = self._argmax_and_copy(l, r, t, b, P)
+        if bad is not None and bool(bad):
+            raise ops.MivosHipError("non-finite probabilities after propagation: an activation left the fp16 range of the f16x3 operands "
+                                    "(|x| >= 65504; INTEGRATION.md 'Limits')? ops.CONV_PRECISION = 'f32' runs the exact fp32 kernels")
+        return masks
+
+    def _argmax_and_copy(self, l, r, t, b, P):
         if self.prob.device == self.device:
             m = ops.argmax_u8(self.prob.view(self.k + 1, self.t * P)).view(self.t, 1, self.nh, self.nw)
             self.masks = m

@@ -213,7 +213,10 @@ class Act:
         return Act(sub, sub.shape[0], self.h, self.w, self.c)
 
 
-_act_scratch = {}
+import collections
+
+_act_scratch = collections.OrderedDict()
+ACT_SCRATCH_ENTRIES = 256   # scratch buffers kept per process (least recently used ones go first)
 USE_ACT_PATH = True     # run conv -> conv edges on the LDS-DMA kernels (needs CONV_PRECISION == "f16x3")
 
 
@@ -236,9 +239,14 @@ def alloc_act(n, h, w, c, device, tag=None):
     key = (tag, n, h, w, c, device.index, torch.cuda.current_stream().cuda_stream)
     a = _act_scratch.get(key)
     if a is None:
-        if len(_act_scratch) >= 256:      # many different clip sizes in one process: start over instead of growing forever
-            _act_scratch.clear()
+        # many different clip sizes in one process (config 4's suite): the least recently used buffer goes, the ones in use stay
+        # (an evicted buffer that a live Act still references is kept alive by that reference; a new one is zeroed on allocation,
+        # so the "border is zero" invariant holds for every buffer handed out)
+        while len(_act_scratch) >= ACT_SCRATCH_ENTRIES:
+            _act_scratch.popitem(last=False)
         a = _act_scratch[key] = Act(torch.zeros((n, h + 2, w + 2, c), dtype=torch.float32, device=device), n, h, w, c)
+    else:
+        _act_scratch.move_to_end(key)
     return a
 
 

@@ -443,6 +443,34 @@ def test_no_topk_network_closed_loop_vs_oracle(synthetic_states):
     assert core.propagated_frames == o32.propagated == 5
 
 
+def test_fp16_range_overflow_is_detected(synthetic_states):
+    """The f16x3 operands are fp16 hi + lo pairs: values beyond +-65504 become inf (INTEGRATION.md "Limits").  A clip whose frames are
+    1e6 times brighter than anything an image normalisation produces must raise instead of returning garbage masks; the exact-fp32
+    mode runs the same clip."""
+    from mivos_amd import ops
+    sd, fsd = synthetic_states
+    prop, fuse = PropagationNetwork(top_k=20), FusionNet()
+    prop.load_state_dict(sd)
+    fuse.load_state_dict(fsd)
+    prop, fuse = prop.to(DEV).eval(), fuse.to(DEV).eval()
+    images, gt = O.synthetic_clip(3, 128, 160, 1, seed=50)
+    with pytest.raises(ops.MivosHipError, match="fp16 range"):
+        InferenceCore(prop, fuse, images * 1e6, 1, device=DEV)
+    # a NaN that reaches the bank mid-clip is caught when the masks are read back
+    core = InferenceCore(prop, fuse, images, 1, device=DEV)
+    core.interact(gt[0], 0)
+    core.prob[1, 2] = float("nan")
+    core._last_propagated = 2
+    with pytest.raises(ops.MivosHipError, match="non-finite"):
+        core._refresh_masks()
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f32"
+    try:
+        out = InferenceCore(prop, fuse, images * 1e6, 1, device=DEV).interact(gt[0], 0)
+    finally:
+        ops.CONV_PRECISION = old
+    assert out.shape == (3, 128, 160)
+
+
 def test_topk_larger_than_memory_raises_like_reference(nets):
     """64x96 frame -> 24 memory positions at T=1 < top_k=50: the reference dies in torch.topk
     ('selected index k out of range'); so do we (SURVEY.md §7 hard part 2)."""
