@@ -477,9 +477,9 @@ def bench_suite(args, torch, ops, shard, rank, world, dev):
                     baseline_config=4, clips=len(specs), parallelism=f"sequence-sharded x{world}", suite_checksum=s["checksum"]),
         roofline=None, cpu_baseline=None, wall_seconds=round(elapsed, 3), busiest_rank_engine_seconds=round(s["busiest_rank_seconds"], 3),
         per_rank=sorted(per_rank.values(), key=lambda r: r["rank"]),
-        # multi-GPU readiness: the measured per-clip cost model (shard.clip_cost assumes frames * (1 + 1.6 * objects)) and the load
+        # multi-GPU readiness: the measured per-clip cost model (shard.clip_cost assumes frames * (1 + 0.32 * objects)) and the load
         # imbalance the longest-first assignment of the FULL 474-clip suite would have at 2 / 4 / 8 ranks under either model
-        cost_model=dict(measured=ES.fit_cost_model(allrecs), assumed_per_object_ratio=1.6,
+        cost_model=dict(measured=ES.fit_cost_model(allrecs), assumed_per_object_ratio=0.32,
                         predicted_imbalance_474_clips=dict(assumed=ES.predicted_imbalance(ES.synthetic_suite(474)),
                                                            measured=(ES.predicted_imbalance(ES.synthetic_suite(474), per_object=ES.fit_cost_model(allrecs)["per_object_ratio"])
                                                                      if ES.fit_cost_model(allrecs) and ES.fit_cost_model(allrecs)["per_object_ratio"] else None))))))

@@ -268,13 +268,13 @@ __global__ void mul_positive_kernel(float *__restrict__ g, const float *__restri
 // torch.optim.Adam (no amsgrad): g += wd * p; m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2;
 // p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v, long long n, float step_size,
-                            float b1, float b2, float eps, float wd, float bc2_sqrt) {
+                            float b1, float b2, float omb1, float omb2, float eps, float wd, float bc2_sqrt) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const float pe = p[e];
   const float g = grad[e] + wd * pe;
-  const float me = b1 * m[e] + (1.f - b1) * g;
-  const float ve = b2 * v[e] + (1.f - b2) * g * g;
+  const float me = b1 * m[e] + omb1 * g;            // omb = 1 - beta, rounded from double like torch's python scalars
+  const float ve = b2 * v[e] + omb2 * g * g;
   m[e] = me; v[e] = ve;
   const float denom = sqrtf(ve) / bc2_sqrt + eps;
   p[e] = pe - step_size * (me / denom);
@@ -338,6 +338,6 @@ extern "C" int mivos_adam_step(float *param, const float *grad, float *exp_avg, 
   // bias corrections in double on the host, like torch.optim.Adam's python scalars
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long long)n, (float)(lr / bc1),
-                     (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)sqrt(bc2));
+                     (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)sqrt(bc2));
   return check_launch("adam_step");
 }

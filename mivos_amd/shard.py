@@ -38,8 +38,10 @@ def init_distributed(backend=None):
 
 def clip_cost(n_frames, n_objects):
     """Relative cost of a clip: every propagated frame costs one object-independent part (query
-    encoder + decoder skip branches) plus a per-object part (memorize + decode), SURVEY.md §8(d)."""
-    return n_frames * (1.0 + 1.6 * n_objects)
+    encoder + decoder skip branches + launch floor) plus a per-object part (memorize + decode), SURVEY.md §8(d).
+    The constant is the measured one: a least-squares fit of per-clip seconds on an MI355X (bench.py --config 4, round 3:
+    2.10 ms + 0.66 ms per object and frame, residuals <= 12 %; the FLOP count alone would say 1.6)."""
+    return n_frames * (1.0 + 0.32 * n_objects)
 
 
 def assign_sequences(costs, world_size):
