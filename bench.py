@@ -307,8 +307,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 8 sessions of configs 2/3, the whole clip of config 5)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps before (default: one session of configs 2/3, 8 steps of config 5)")
-    ap.add_argument("--config", type=lambda v: v if v == "s2m" else int(v), default=3, choices=(2, 3, 4, 5, "s2m"),
-                    help="2 / 3 / 4 / 5: BASELINE configs; s2m: the scribble-to-mask step in front of the path (SURVEY 8(f)1)")
+    ap.add_argument("--config", type=lambda v: v if v in ("s2m", "train") else int(v), default=3, choices=(2, 3, 4, 5, "s2m", "train"),
+                    help="2 / 3 / 4 / 5: BASELINE configs; s2m: the scribble-to-mask step in front of the path (SURVEY 8(f)1); "
+                         "train: FusionNet training iterations (SURVEY 8(f)4), data parallel over the ranks")
     ap.add_argument("--frames", type=int, default=None, help="clip length override (config 5: default 1000)")
     ap.add_argument("--objects", type=int, default=None)
     ap.add_argument("--top-k", type=int, default=None)
@@ -352,6 +353,8 @@ def main():
         return bench_suite(args, torch, ops, shard, rank, world, dev)
     if args.config == "s2m":
         return bench_s2m(args, torch, ops, shard, rank, world, dev)
+    if args.config == "train":
+        return bench_train(args, torch, ops, shard, rank, world, dev, local)
 
     cfg = dict(CONFIGS[args.config])
     for key, val in (("frames", args.frames), ("objects", args.objects), ("top_k", args.top_k)):
@@ -516,6 +519,44 @@ def bench_s2m(args, torch, ops, shard, rank, world, dev):
                                                                   f"forward = the scribble-to-mask work of one interaction with {K} objects",
                                                         objects=K, height=480, width=864, parallelism=f"replicas x{world}"),
                           roofline=None, cpu_baseline=None, logit_range=[round(float(out.min()), 2), round(float(out.max()), 2)])))
+
+
+def bench_train(args, torch, ops, shard, rank, world, dev, local):
+    """--config train: FusionModel.do_pass iterations (model/fusion_model.py:54-131) on a synthetic batch of 384 x 384 crops
+    (dataset/fusion_dataset.py:61), `--objects` samples per rank (default 4), data parallel: each rank its own batch, the flat
+    gradient all-reduced (RCCL) every step.  step = one iteration (attention maps + forward + loss + backward + all-reduce + Adam)."""
+    from mivos_amd.model.fusion_model import FusionModel
+    from mivos_amd.util import synthetic
+    B = args.objects or 4
+    torch.set_grad_enabled(False)
+    model = FusionModel(dict(lr=1e-4, steps=[20000], gamma=0.1, iterations=30000), local_rank=local, world_size=world, distributed=world > 1)
+    sd = synthetic.make_prop_state(0)
+    model.net.load_state_dict(synthetic.make_fuse_state(0))
+    model.prop_net.load_state_dict({k: v for k, v in sd.items() if not k.startswith("decoder.")}, strict=False)
+    data = synthetic.synthetic_fusion_batch(B, 384, 384, seed=rank, device=dev)
+    warmup, steps = args.warmup if args.warmup is not None else 2, args.steps if args.steps is not None else 10
+    it0 = 10000                                                          # inside BootstrappedCE's warm-up window (top-p selection active)
+    losses = []
+    for i in range(warmup):
+        losses.append(float(model.do_pass(dict(data), it0 + i)["losses"]["total_loss"]))
+    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = model.do_pass(dict(data), it0 + warmup + i)
+    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
+    losses.append(float(out["losses"]["total_loss"]))
+    recs = shard.gather_records([dict(rank=rank, param_checksum=float(model.flat.double().sum()), first_loss=losses[0], last_loss=losses[-1])])
+    if rank != 0:
+        return
+    print(json.dumps(dict(metric="FusionNet training iterations/sec", value=round(steps / elapsed, 3), unit="iterations/s", n_gpus=world, steps=steps,
+                          warmup=warmup, ms_per_step=round(elapsed / steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+                          dtype="f16x3 forward / data gradients, exact fp32 MFMA weight gradients, fp32 loss and Adam", data="synthetic",
+                          config=dict(workload=f"fusion_training (model/fusion_model.py:54-131): {B} samples of 384x384 per rank (2 FusionNet calls each), "
+                                               f"BootstrappedCE inside its warm-up, Adam, one all-reduce of 39 905 gradients per step",
+                                      batch_per_rank=B, global_batch=B * world, parallelism=f"data-parallel x{world}"),
+                          roofline=None, cpu_baseline=None, per_rank=recs,
+                          replicas_in_sync=len({r["param_checksum"] for r in recs}) == 1)))
 
 
 def bench_generator(args, torch, shard, ES, specs, prop, rank, world, dev):

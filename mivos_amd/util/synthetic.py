@@ -292,3 +292,33 @@ def synthetic_clip_device(t, h, w, k, seed=0, device="cuda", chunk=64):
         for j in range(k + 1):
             masks[i, j, 0] = (label == j).float()
     return images, masks
+
+
+def synthetic_fusion_batch(b, h, w, seed=0, device="cpu"):
+    """A batch in the layout of dataset/fusion_dataset.py:225-249 (the FusionNet training input): smooth random masks for two objects
+    (every other sample has no second object: selector [1, 0]), noisy soft propagations of them, normalised random frames."""
+    g = torch.Generator().manual_seed(4321 + seed)
+
+    def blobs(thr):
+        z = F.interpolate(torch.randn(b, 1, h // 8, w // 8, generator=g), size=(h, w), mode="bilinear", align_corners=False)
+        return (z > thr).float()
+
+    def soft(m):
+        return (m * 0.8 + 0.1 + 0.1 * torch.randn(m.shape, generator=g)).clamp(0, 1)
+
+    gt1, gt2 = blobs(0.3), blobs(0.5)
+    gt2 = gt2 * (1 - gt1)
+    data = dict(rgb=torch.randn(b, 3, h, w, generator=g), src2_ref_im=torch.randn(b, 3, h, w, generator=g), gt=gt1, gt2=gt2,
+                seg1=soft(gt1), seg2=soft(blobs(0.3)), src2_ref=soft(gt1), src2_ref_gt=blobs(0.3),
+                seg12=soft(gt2), seg22=soft(blobs(0.5)), src2_ref2=soft(gt2), src2_ref_gt2=blobs(0.5),
+                dist=torch.rand(b, 1, generator=g).repeat(1, 2), selector=torch.ones(b, 2))
+    data["dist"][:, 1] = 1 - data["dist"][:, 0]
+    for j in range(1, b, 2):
+        data["selector"][j, 1] = 0
+        for k in ("gt2", "seg12", "seg22", "src2_ref2", "src2_ref_gt2"):
+            data[k][j] = 0
+    cls = torch.zeros(b, h, w, dtype=torch.long)
+    cls[data["gt"][:, 0] > 0.5] = 1
+    cls[data["gt2"][:, 0] > 0.5] = 2
+    data["cls_gt"] = cls
+    return {k: v.to(device) for k, v in data.items()}
