@@ -308,8 +308,11 @@ class OracleCore:
     call.  ``logits`` keeps the decoder logits of the last pass per frame for
     tolerance checks."""
 
-    def __init__(self, sd, fsd, images, num_objects, mem_freq=5, top_k=50, dtype=torch.float32):
+    def __init__(self, sd, fsd, images, num_objects, mem_freq=5, top_k=50, dtype=torch.float32, record_margins=False):
         self.sd, self.fsd, self.top_k, self.dtype = sd, fsd, top_k, dtype
+        # record_margins: per propagated frame the smallest gap between the k-th and (k+1)-th affinity of any query / object
+        # (test diagnostics: a gap below the rounding noise of the keys means top-k membership is decided by that noise)
+        self.record_margins, self.topk_margin = record_margins, {}
         self.mem_freq, self.k = mem_freq, num_objects
         self.t = images.shape[1]
         self.h, self.w = images.shape[-2:]
@@ -355,7 +358,13 @@ class OracleCore:
             m = m_front if prev_in_mem else m_front + 1
             q = self._query(ti)
             self.trace.append(f"S{m}")
+            global TOPK_GAP
+            if self.record_margins:
+                TOPK_GAP = []
             logit = segment_logits(self.sd, keys[:, :, :m], values[:, :, :m], *q, self.top_k)
+            if self.record_margins:
+                self.topk_margin[ti] = min(TOPK_GAP) if TOPK_GAP else float("inf")
+                TOPK_GAP = None
             self.logits[ti] = logit
             out = aggregate_wbg(torch.sigmoid(logit), keep_bg=True)
             if ti != end:
@@ -407,8 +416,9 @@ class OracleGenerator:
     """Restatement of FusionGenerator (generation/fusion_generator.py:12-101): propagation from one annotated frame to both range
     limits, no fusion, no query cache; the bank grows by torch.cat with a temporary entry for the previous frame."""
 
-    def __init__(self, sd, images, mem_freq, top_k=50, dtype=torch.float32):
+    def __init__(self, sd, images, mem_freq, top_k=50, dtype=torch.float32, record_margins=False):
         self.sd, self.mem_freq, self.top_k, self.dtype = sd, mem_freq, top_k, dtype
+        self.record_margins, self.topk_margin = record_margins, {}
         self.t = images.shape[1]
         self.h, self.w = images.shape[-2:]
         self.images, self.pad = pad_divide_by(images.to(dtype), 16)                       # :22
@@ -430,7 +440,13 @@ class OracleGenerator:
             this_k = keys if prev_k is None else torch.cat([keys, prev_k], 2)
             this_v = values if prev_v is None else torch.cat([values, prev_v], 2)
             q = get_query_values(self.sd, self.images[:, ti])
+            global TOPK_GAP
+            if self.record_margins:
+                TOPK_GAP = []
             out = aggregate_wbg(segment_with_query(self.sd, this_k, this_v, *q, top_k=self.top_k), keep_bg=True)
+            if self.record_margins:
+                self.topk_margin[ti] = min(TOPK_GAP) if TOPK_GAP else float("inf")
+                TOPK_GAP = None
             self.prob[:, ti] = out
             if ti != end:
                 prev_k, prev_v = memorize(self.sd, self.images[:, ti], out[1:])

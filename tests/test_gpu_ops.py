@@ -344,7 +344,8 @@ def test_fusion_head_exact_fp32(B, H, W):
     assert rel_err(nb.cpu().permute(0, 3, 1, 2), ref - b.double()) < 1e-6
 
 
-@pytest.mark.parametrize("N,n_planes,cin,H,W", [(1, 3, 4, 64, 96), (2, 5, 8, 50, 70), (5, 5, 8, 480, 864), (8, 3, 4, 128, 160), (1, 5, 8, 17, 33)])
+@pytest.mark.parametrize("N,n_planes,cin,H,W", [(1, 3, 4, 64, 96), (2, 5, 8, 50, 70), (5, 5, 8, 480, 864), (8, 3, 4, 128, 160), (1, 5, 8, 17, 33),
+                                                 (1, 5, 8, 480, 864), (3, 3, 4, 480, 864)])
 def test_stem_from_planes(N, n_planes, cin, H, W):
     """mivos_stem7x7s2_planes (7x7 / 2 / pad 3 conv + BN + ReLU straight from planar inputs: the stems of the query encoder - 3
     planes, Cin padded to 4 - and of the mask encoder - frame planes shared by all objects + per-object mask / others planes) vs
