@@ -200,7 +200,8 @@ struct SelectArgs {
   long long total_tiles;
   int tiles_per_wg, slots, L;
   int *header;               // first 64 bytes of the workspace: the plan this launch used, for the finalize kernel
-  int qt;                    // queries per workgroup (QT, or QT2 for the 32-queries-per-wave kernel)
+  int qt;                    // queries per workgroup (QT, QT2 for the 32-queries-per-wave kernel, QT3 for the 8-wave one)
+  uint64_t *cand;            // QT3 kernel: global candidate regions, CAND3_PER_WG entries per workgroup
   unsigned long long *dbg;   // profiling builds: {shader cycles, tiles} of workgroup 0 / wave 0 (NULL otherwise)
 };
 
@@ -808,6 +809,205 @@ __global__ __launch_bounds__(256, 1) void memread_select32_kernel(const SelectAr
   }
 }
 
+// ---- the 256-queries-per-workgroup variant for very long memories -------------------------------------------------------
+// memread_select32_kernel is bound by the L2 -> CU key stream: every 128-query workgroup re-reads its object's whole key bank
+// (80 GB of L2 requests per launch at 1080p, T = 100).  More queries per key byte need more candidate storage than LDS has
+// (256 queries x 2 regions x 61 entries x 8 B = 250 KB), so here the lane-private candidate regions live in GLOBAL scratch:
+// once the thresholds have converged (a few hundred positions into a stream of 10^5 - 10^6) almost no score passes, the
+// append is a rare exec-masked global store and a compaction a rare round trip to L2.  LDS then only holds the two key tiles.
+//   8 waves x 32 queries per workgroup (two waves per SIMD: one fills the matrix pipe while the other reads its fragments and
+//   selects); 256 VGPRs per wave, so one fragment set (read at the start of a tile) and one accumulator pair; tile t + 1 is
+//   written to the other LDS buffer during tile t (requested 4 tiles ahead, explicit vmcnt as above), one barrier per tile.
+//   A wave's own global stores are ordered before its later loads by a workgroup-scope fence (same CU, same L1) and the
+//   reads bypass L1 (agent-scope loads) for good measure.  The explicit `s_waitcnt vmcnt(N)` of the key pipeline stays
+//   correct with stores in flight: they only add to the count, and the count cannot fall to N before the oldest loads landed.
+constexpr int NW3 = 8, QT3 = 256, REG3 = 61, REG3_TRIGGER = REG3 - 1 - 8, STAGE_DEPTH3 = 4;
+constexpr long long CAND3_PER_WG = (long long)NW3 * 2 * 32 * REG3;      // candidate entries (8 bytes each) per workgroup
+
+__device__ __forceinline__ uint64_t gload_entry(const uint64_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int compact_query_g(uint64_t *buf, int n0, int n1, int k, int lane, float &new_tau) {
+  constexpr int GS = 32 * REG3;                        // region h of this query starts at buf + h * GS
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  uint64_t raw[2], e[2];
+  raw[0] = lane < n0 ? gload_entry(buf + lane) : 0ull;
+  raw[1] = lane < n1 ? gload_entry(buf + GS + lane) : 0ull;
+  e[0] = lane < n0 ? raw_to_key(raw[0]) : 0ull;
+  e[1] = lane < n1 ? raw_to_key(raw[1]) : 0ull;
+  int c = n0 + n1;
+  uint64_t p = 1ull;                                   // one region nearly full, few entries overall: only rebalance
+  if (c > k + SLACK) p = bisect_kth<2>(e, k, SLACK, c);
+  int base = 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const bool keep = e[t] >= p;
+    const unsigned long long m = __ballot(keep);
+    const int r = base + __popcll(m & below);         // rank among the survivors -> region r & 1, slot r >> 1
+    if (keep) buf[(r & 1) * GS + (r >> 1)] = raw[t];
+    base += __popcll(m);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  if (p != 1ull) new_tau = ord2f((uint32_t)(p >> 32));
+  return c;
+}
+
+__global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectArgs a) {
+  __shared__ __attribute__((aligned(16))) float ktile[2][KT * KLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int qslot = wave * 32 + j;
+  const int lrow = tid >> 4, lc = tid & 15;          // key-tile loader: row tid >> 4, float4 columns lc and lc + 16
+
+  long long t_begin = (long long)blockIdx.x * a.tiles_per_wg;
+  const long long t_end = (t_begin + a.tiles_per_wg < a.total_tiles) ? t_begin + a.tiles_per_wg : a.total_tiles;
+  write_plan_header(a);
+  uint64_t *const wave_regions = a.cand + ((long long)blockIdx.x * NW3 + wave) * (2 * 32 * REG3);   // [h][j][REG3]
+  uint64_t *const my_region = wave_regions + (h * 32 + j) * REG3;
+
+  while (t_begin < t_end) {
+    const int stream = (int)(t_begin / a.tps);
+    const int seg_lo = (int)(t_begin - (long long)stream * a.tps);
+    int seg_hi = seg_lo + (int)(t_end - t_begin);
+    if (seg_hi > a.tps) seg_hi = a.tps;
+    const int nt = seg_hi - seg_lo;
+    const int obj = stream / a.n_qtiles, qtile = stream - obj * a.n_qtiles;
+    const int slot = (int)blockIdx.x - (int)(((long long)stream * a.tps) / a.tiles_per_wg);
+    const int r0 = seg_lo * KT;
+    const int r1 = ((long long)seg_hi * KT < a.n_mem) ? seg_hi * KT : (int)a.n_mem;
+    const float *kbase = a.keys + (long long)obj * a.keys_ostride;
+
+    __syncthreads();                                  // previous segment completely done with LDS
+
+    f32x4_t qf[16];                                   // B operand: query j, scaled like prop_net.py:86, split hi/lo (see memread_select32_kernel)
+    {
+      const int q = qtile * QT3 + qslot;
+      const float *qrow = a.qk + (long long)(q < a.n_q ? q : a.n_q - 1) * CK + 32 * h;
+      const float d = sqrtf((float)CK);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const float *src = qrow + 64 * (ks & 1) + 8 * (ks >> 1);
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t *>(src), v1 = *reinterpret_cast<const f32x4_t *>(src + 4);
+        half8_t hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = (e < 4 ? v0[e & 3] : v1[e & 3]) / d;
+          hi[e] = (_Float16)x;
+          lo[e] = (_Float16)(x - (float)hi[e]);
+        }
+        qf[2 * ks] = __builtin_bit_cast(f32x4_t, hi);
+        qf[2 * ks + 1] = __builtin_bit_cast(f32x4_t, lo);
+      }
+#pragma unroll
+      for (int x = 0; x < 16; ++x) asm volatile("" : "+v"(qf[x]));      // finished before the key requests go out
+    }
+
+    f32x4_t kr[STAGE_DEPTH3][2];
+    auto gload = [&](f32x4_t (&krs)[2], int kb) {
+      const int m = kb + lrow;                        // rows past the segment's end: its first row instead (never selected)
+      const f32x4_t *src = reinterpret_cast<const f32x4_t *>(kbase + (long long)(m < r1 ? m : r0) * CK) + lc;
+      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:256"
+                   : "=&v"(krs[0]), "=&v"(krs[1]) : "v"(src) : "memory");
+    };
+    auto lds_store = [&](f32x4_t (&krs)[2], int buf) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) *reinterpret_cast<f32x4_t *>(&ktile[buf][lrow * KLD + 4 * (lc + 16 * jj)]) = krs[jj];
+    };
+
+    float my_tau = -INFINITY;
+    int my_cnt = 0;
+    auto compact_one = [&](int ql, bool force) {
+      const int n0 = __builtin_amdgcn_readlane(my_cnt, ql), n1 = __builtin_amdgcn_readlane(my_cnt, ql + 32);
+      if (force && n0 + n1 <= a.top_k + SLACK) return;
+      float nt_tau = my_tau;
+      const int c = compact_query_g(wave_regions + ql * REG3, n0, n1, a.top_k, lane, nt_tau);
+      if (j == ql) { my_cnt = (c - h + 1) >> 1; my_tau = nt_tau; }
+    };
+    auto make_room = [&]() {
+      const unsigned long long full = __ballot(my_cnt > REG3_TRIGGER);
+      unsigned need = (unsigned)(full | (full >> 32));
+      while (need) {
+        const int ql = __builtin_ctz(need);
+        need &= need - 1;
+        compact_one(ql, false);
+      }
+    };
+
+    // prologue: tile 0 into LDS buffer 0, tiles 1 .. STAGE_DEPTH3 requested (tile i -> register set i % STAGE_DEPTH3)
+    gload(kr[0], r0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_store(kr[0], 0);
+#pragma unroll
+    for (int d = 1; d <= STAGE_DEPTH3; ++d) gload(kr[d % STAGE_DEPTH3], r0 + d * KT);
+    __syncthreads();
+
+    // one tile: tile t + 1 (requested STAGE_DEPTH3 tiles ago) goes to the other LDS buffer (tile t - 1's copy, whose readers passed
+    // the barrier of iteration t - 1) and its registers take the request for tile t + 1 + STAGE_DEPTH3; fragments of tile t, 24
+    // MFMAs, selection of its 16 scores per lane; barrier.
+    auto tile_iter = [&](int t, f32x4_t (&krs)[2]) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (STAGE_DEPTH3 - 1)) : "memory");
+      lds_store(krs, (t + 1) & 1);
+      gload(krs, r0 + (t + 1 + STAGE_DEPTH3) * KT);
+      const float *arow = &ktile[t & 1][j * KLD + 8 * h];
+      f32x4_t fa[16];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        fa[2 * ks] = *reinterpret_cast<const f32x4_t *>(arow + 16 * ks);
+        fa[2 * ks + 1] = *reinterpret_cast<const f32x4_t *>(arow + 16 * ks + 4);
+      }
+      f32x16_t acc[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {                 // lo*hi, hi*lo, hi*hi on two alternating accumulators (memread_select32_kernel)
+        acc[(3 * ks) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[2 * ks + 1]), __builtin_bit_cast(half8_t, qf[2 * ks]), acc[(3 * ks) & 1], 0, 0, 0);
+        acc[(3 * ks + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[2 * ks]), __builtin_bit_cast(half8_t, qf[2 * ks + 1]), acc[(3 * ks + 1) & 1], 0, 0, 0);
+        acc[(3 * ks + 2) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[2 * ks]), __builtin_bit_cast(half8_t, qf[2 * ks]), acc[(3 * ks + 2) & 1], 0, 0, 0);
+      }
+      // (the hazard guard of memread_select32_kernel: MFMA results read by the vector ALU behind a branch)
+      asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+      const int pb = r0 + t * KT;
+      const uint32_t idx_base = (uint32_t)(pb + 4 * h);
+      const bool tail = pb + KT > r1;                 // only the last tile of a stream can hold rows past the end of the memory
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (r == 0 || r == 8) make_room();
+        float sc = acc[0][r] + acc[1][r];
+        if (tail && pb + 4 * h + 8 * (r >> 2) + (r & 3) >= r1) sc = -INFINITY;
+        const bool pass = sc > my_tau;
+        if (__ballot(pass)) {                          // wave-uniform: almost never taken once the thresholds have converged
+          if (pass) my_region[my_cnt] = ((uint64_t)__float_as_uint(sc) << 32) | (uint64_t)(idx_base + (uint32_t)(8 * (r >> 2) + (r & 3)));
+          my_cnt += pass ? 1 : 0;
+        }
+      }
+      __syncthreads();
+    };
+    for (int t = 0; t < nt; t += STAGE_DEPTH3) {
+      tile_iter(t, kr[1 % STAGE_DEPTH3]);
+      if (t + 1 < nt) tile_iter(t + 1, kr[2 % STAGE_DEPTH3]);
+      if (t + 2 < nt) tile_iter(t + 2, kr[3 % STAGE_DEPTH3]);
+      if (t + 3 < nt) tile_iter(t + 3, kr[0]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the requests past the end of the segment: their registers are reused
+
+    // this segment's candidate lists: for each of the wave's 32 queries between min(n, k) and k + SLACK entries
+    for (int ql = 0; ql < 32; ++ql) {
+      compact_one(ql, true);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      const int n0 = __builtin_amdgcn_readlane(my_cnt, ql), n1 = __builtin_amdgcn_readlane(my_cnt, ql + 32);
+      const int s = wave * 32 + ql;
+      const uint64_t *src = wave_regions + ql * REG3;               // region h at src + h * 32 * REG3
+      uint64_t *dst = a.lists + (((long long)stream * a.slots + slot) * QT3 + s) * a.L;
+      if (lane < n0) dst[lane] = raw_to_key(gload_entry(src + lane));
+      if (lane < n1) dst[n0 + lane] = raw_to_key(gload_entry(src + 32 * REG3 + lane));
+      for (int i = n0 + n1 + lane; i < a.L; i += 64) dst[i] = 0ull;
+    }
+    t_begin += nt;
+  }
+}
+
 // optional SH32 outputs of the readout (zero-bordered activation buffers of the LDS-DMA convolutions): raw and relu(raw),
 // addressed as image `obj`, pixel (q / q_width, q % q_width); strides in floats
 struct ShOut {
@@ -998,9 +1198,31 @@ static long long q128_min() {
   }
   return v;
 }
-static int select_qt(bool f16, long long n_mem) { return (f16 && n_mem >= q128_min()) ? QT2 : QT; }
+static std::atomic<long long> g_q256_min{-1};     // ... and from which the 256-query plan (candidate regions in global scratch) takes over
+static long long q256_min() {
+  long long v = g_q256_min.load(std::memory_order_relaxed);
+  if (v < 0) {
+    v = getenv("MIVOS_MEMREAD_Q256_MIN") ? atoll(getenv("MIVOS_MEMREAD_Q256_MIN")) : (1ll << 60);
+    g_q256_min.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+static int select_qt(bool f16, long long n_mem) {
+  if (f16 && n_mem >= q256_min()) return QT3;
+  return (f16 && n_mem >= q128_min()) ? QT2 : QT;
+}
 
 static long long lists_bytes(const Plan &p) { return (long long)p.streams * p.slots * p.qt * p.L * 8; }
+// workspace layout: [64-byte header][candidate lists of the largest plan][candidate regions of the 256-query kernel]
+static long long max_lists_bytes(int n_obj, long long n_mem, int n_q, int top_k) {
+  long long m = 0;
+  for (int qt : {QT, QT2, QT3}) {
+    const long long b = lists_bytes(make_plan(n_obj, n_mem, n_q, top_k, qt));
+    m = b > m ? b : m;
+  }
+  return (m + 255) / 256 * 256;
+}
+static long long cand3_bytes() { return (long long)compute_units() * CAND3_PER_WG * 8; }
 
 static int check_select_args(const float *keys, int64_t keys_ostride, const float *qk, int n_obj, int64_t n_mem, int n_q,
                              int top_k, void *workspace, int64_t workspace_bytes) {
@@ -1026,8 +1248,9 @@ static void launch_finalize_n(void *workspace, const float *values, int64_t valu
 static int launch_finalize(bool indices, void *workspace, const float *values, int64_t values_ostride, float *out,
                            int64_t out_ostride, int64_t out_pstride, int32_t *idx_out, float *w_out, int n_obj, int64_t n_mem, int n_q, int top_k,
                            hipStream_t st, const ShOut &sh = ShOut{nullptr, nullptr, 0, 0, 0, 1}) {
-  const Plan p64 = make_plan(n_obj, n_mem, n_q, top_k, QT), p128 = make_plan(n_obj, n_mem, n_q, top_k, QT2);
-  const int slots = p64.slots > p128.slots ? p64.slots : p128.slots;
+  const Plan p64 = make_plan(n_obj, n_mem, n_q, top_k, QT), p128 = make_plan(n_obj, n_mem, n_q, top_k, QT2), p256 = make_plan(n_obj, n_mem, n_q, top_k, QT3);
+  int slots = p64.slots > p128.slots ? p64.slots : p128.slots;
+  slots = p256.slots > slots ? p256.slots : slots;
   const int per_lane = cdiv((long long)slots * p64.L, 64);       // slots bounds the segments of any stream
 #define MIVOS_FIN(N)                                                                                                              \
   (indices ? launch_finalize_n<true, N>(workspace, values, values_ostride, out, out_ostride, out_pstride, idx_out, w_out, n_obj, n_q, top_k, st, sh) \
@@ -1052,8 +1275,13 @@ using namespace mivos;
 
 extern "C" int64_t mivos_memory_read_workspace_bytes(int n_obj, int64_t n_mem, int n_q, int top_k) {
   if (n_obj < 1 || n_q < 1 || n_mem < 1 || top_k < 1) return 0;
-  const long long a = lists_bytes(make_plan(n_obj, n_mem, n_q, top_k, QT)), b = lists_bytes(make_plan(n_obj, n_mem, n_q, top_k, QT2));
-  return HEADER_BYTES + (a > b ? a : b);
+  return HEADER_BYTES + max_lists_bytes(n_obj, n_mem, n_q, top_k) + cand3_bytes();
+}
+
+extern "C" int64_t mivos_memory_read_set_q256_min(int64_t n_mem_min) {
+  const long long old = q256_min();
+  if (n_mem_min >= 0) g_q256_min.store(n_mem_min, std::memory_order_relaxed);
+  return old;
 }
 
 extern "C" int64_t mivos_memory_read_set_q128_min(int64_t n_mem_min) {
@@ -1080,6 +1308,7 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
   a.lists = (uint64_t *)((char *)workspace + HEADER_BYTES); a.n_mem = n_mem; a.n_q = n_q;
   a.top_k = top_k; a.n_qtiles = pl.n_qtiles; a.tps = pl.tps; a.total_tiles = pl.total; a.tiles_per_wg = pl.tiles_per_wg;
   a.slots = pl.slots; a.L = pl.L; a.qt = qt;
+  a.cand = (uint64_t *)((char *)workspace + HEADER_BYTES + max_lists_bytes(n_obj, n_mem, n_q, top_k));
   static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;          // profiling only
   static const int dbg = getenv("MIVOS_MEMREAD_DBG") ? atoi(getenv("MIVOS_MEMREAD_DBG")) : 0;   // profiling only: prints cycles per tile
   static unsigned long long *dbg_buf = nullptr;
@@ -1095,7 +1324,10 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
   hipStream_t st = (hipStream_t)stream;
 #define MIVOS_SEL(ABL, BR, F16) hipLaunchKernelGGL((memread_select_kernel<ABL, BR, F16>), grid, block, 0, st, a)
 #define MIVOS_SEL32(ABL, BR) hipLaunchKernelGGL((memread_select32_kernel<ABL, BR>), grid, block, 0, st, a)
-  if (qt == QT2) {
+  if (qt == QT3) {
+    if ((long long)pl.n_wg * CAND3_PER_WG * 8 > cand3_bytes()) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read: more workgroups than candidate scratch");
+    hipLaunchKernelGGL(memread_select256_kernel, grid, dim3(512), 0, st, a);
+  } else if (qt == QT2) {
     if (abl == 1) MIVOS_SEL32(1, false);
     else if (br) MIVOS_SEL32(0, true);
     else MIVOS_SEL32(0, false);

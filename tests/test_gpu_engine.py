@@ -45,7 +45,7 @@ def mean_iou(a, b, k):
 
 
 ARBITRATION_FACTOR, ARBITRATION_FLOOR = 2.0, 2.5e-4
-TIE_MARGIN, TIE_QUANTILE, TIE_CAP = 1e-3, 1e-4, 5e-2
+TIE_MARGIN, TIE_QUANTILE, TIE_CAP = 1e-3, 5e-3, 5e-2
 
 
 def fp64_gate(tag, eng_prob, ref32_prob, ref64_prob, margins=None):
@@ -62,8 +62,9 @@ def fp64_gate(tag, eng_prob, ref32_prob, ref64_prob, margins=None):
     those sessions - and only for them: `margins` holds, per propagated frame, the smallest rank-k / k+1 gap of the fp64 run; a frame
     qualifies when that gap is below TIE_MARGIN = 1e-3 somewhere in the session so far (flips travel through the memory bank) -
 
-      tie clause      all but TIE_QUANTILE = 1e-4 of the frame's pixels obey the strict bound (quantile against quantile),
-                      and max e_f <= TIE_CAP = 5e-2 (what one flipped neighbour of weight ~1/k can move)
+      tie clause      all but TIE_QUANTILE = 5e-3 of the frame's pixels obey the strict bound (quantile against quantile: one
+                      flipped neighbour at the 1/16-resolution grid reaches ~32 x 32 output pixels through the decoder, 0.25 % of a
+                      480p frame), and max e_f <= TIE_CAP = 5e-2 (what a flipped neighbour of weight ~1/k can move)
 
     Prints the numbers, appends them to gpurun_out/parity_ratios.jsonl (a record per run) and returns (passed, record)."""
     e = (eng_prob.cpu().double() - ref64_prob).abs()
@@ -88,7 +89,8 @@ def fp64_gate(tag, eng_prob, ref32_prob, ref64_prob, margins=None):
         et, rt = e[:, t].reshape(-1), r[:, t].reshape(-1)
         kth = max(1, int(round(et.numel() * (1.0 - TIE_QUANTILE))))
         e_q, r_q = float(et.kthvalue(kth).values), float(rt.kthvalue(kth).values)
-        eq.append(e_q); rq.append(r_q)
+        eq.append([e_q] + [float(et.kthvalue(max(1, int(round(et.numel() * (1.0 - qq))))).values) for qq in (1e-3, 1e-4)])   # at 5e-3, 1e-3, 1e-4
+        rq.append([r_q] + [float(rt.kthvalue(max(1, int(round(rt.numel() * (1.0 - qq))))).values) for qq in (1e-3, 1e-4)])
         near_tie = margins is not None and min(seen.values(), default=float("inf")) < TIE_MARGIN
         if near_tie and e_q <= ARBITRATION_FACTOR * r_q + ARBITRATION_FLOOR and float(ef[t]) <= TIE_CAP:
             clause.append("tie")
@@ -100,7 +102,7 @@ def fp64_gate(tag, eng_prob, ref32_prob, ref64_prob, margins=None):
                min_topk_margin_fp64=(min(margins.values()) if margins else None),
                frac_gt_1e3_engine=float((e > 1e-3).double().mean()), frac_gt_1e3_ref32=float((r > 1e-3).double().mean()),
                per_frame_engine=[float(x) for x in ef], per_frame_ref32=[float(x) for x in rf],
-               per_frame_engine_q9999=eq, per_frame_ref32_q9999=rq)
+               per_frame_engine_quantiles=eq, per_frame_ref32_quantiles=rq)
     print(f"{tag}: per-frame max|dprob| engine-fp64 {rec['engine_vs_fp64_max']:.2e} vs reference(fp32)-fp64 {rec['ref32_vs_fp64_max']:.2e}; "
           f"worst per-frame ratio {ratio:.2f} (strict gate: e <= {ARBITRATION_FACTOR} r + {ARBITRATION_FLOOR}, margin {margin:.2e}); clauses {sorted(set(clause))}; "
           f"min fp64 top-k margin {rec['min_topk_margin_fp64']}; frac(|d| > 1e-3) engine {rec['frac_gt_1e3_engine']:.1e} reference {rec['frac_gt_1e3_ref32']:.1e}")
