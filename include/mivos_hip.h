@@ -271,7 +271,7 @@ int mivos_memory_read_topk(const float *keys, int64_t keys_ostride, const float 
 /* How a select launch cuts the work (host logic, no GPU needed; tests / profilers): plan_out[7] = {workgroups, tiles of
  * 32 memory positions per workgroup, candidate lists per stream, tiles per stream, streams (= n_obj * ceil(n_q / queries per
  * workgroup)), entries per list, queries per workgroup}.  f16x3 = 0: mivos_memory_read_select (64 queries per workgroup);
- * 1: mivos_memory_read_select_f16x3 (64, or 128 for long memories).  Workgroup w takes tiles
+ * 1: mivos_memory_read_select_f16x3 (64; 128 / 256 for long memories, see the two setters below).  Workgroup w takes tiles
  * [w * tiles_per_wg, (w + 1) * tiles_per_wg) of the concatenated streams.  The select kernels leave the plan they used in the
  * first 64 bytes of the workspace, where the finalize kernels read it. */
 int mivos_memory_read_plan(int n_obj, int64_t n_mem, int n_q, int top_k, int f16x3, int32_t *plan_out);
@@ -279,7 +279,7 @@ int mivos_memory_read_plan(int n_obj, int64_t n_mem, int n_q, int top_k, int f16
  * kernel (default 400000, or the environment variable MIVOS_MEMREAD_Q128_MIN); returns the previous value, negative = only query. */
 int64_t mivos_memory_read_set_q128_min(int64_t n_mem_min);
 /* ... and the depth from which it uses the 256-queries-per-workgroup kernel (8 waves, candidate regions in global scratch inside the
- * workspace; environment variable MIVOS_MEMREAD_Q256_MIN). */
+ * workspace; default 400000 = it takes precedence over the 128-query kernel, environment variable MIVOS_MEMREAD_Q256_MIN). */
 int64_t mivos_memory_read_set_q256_min(int64_t n_mem_min);
 int mivos_memory_read_select(const float *keys, int64_t keys_ostride, const float *qk, int n_obj,
                              int64_t n_mem, int n_q, int top_k, void *workspace, int64_t workspace_bytes,

@@ -816,12 +816,13 @@ __global__ __launch_bounds__(256, 1) void memread_select32_kernel(const SelectAr
 // once the thresholds have converged (a few hundred positions into a stream of 10^5 - 10^6) almost no score passes, the
 // append is a rare exec-masked global store and a compaction a rare round trip to L2.  LDS then only holds the two key tiles.
 //   8 waves x 32 queries per workgroup (two waves per SIMD: one fills the matrix pipe while the other reads its fragments and
-//   selects); 256 VGPRs per wave, so one fragment set (read at the start of a tile) and one accumulator pair; tile t + 1 is
-//   written to the other LDS buffer during tile t (requested 4 tiles ahead, explicit vmcnt as above), one barrier per tile.
+//   selects); 256 VGPRs per wave, so one fragment set (read at the start of a tile), two accumulator pairs (tile t - 1 is selected
+//   between the MFMAs of tile t, like in memread_select32_kernel) and two key tiles in flight; tile t + 1 is written to the other LDS
+//   buffer during tile t (explicit vmcnt as above), one barrier per tile.
 //   A wave's own global stores are ordered before its later loads by a workgroup-scope fence (same CU, same L1) and the
 //   reads bypass L1 (agent-scope loads) for good measure.  The explicit `s_waitcnt vmcnt(N)` of the key pipeline stays
 //   correct with stores in flight: they only add to the count, and the count cannot fall to N before the oldest loads landed.
-constexpr int NW3 = 8, QT3 = 256, REG3 = 61, REG3_TRIGGER = REG3 - 1 - 8, STAGE_DEPTH3 = 4;
+constexpr int NW3 = 8, QT3 = 256, REG3 = 61, REG3_TRIGGER = REG3 - 1 - 8, STAGE_DEPTH3 = 2;   // (2 key tiles in flight: 256 VGPRs per wave)
 constexpr long long CAND3_PER_WG = (long long)NW3 * 2 * 32 * REG3;      // candidate entries (8 bytes each) per workgroup
 
 __device__ __forceinline__ uint64_t gload_entry(const uint64_t *p) {
@@ -943,10 +944,24 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
     for (int d = 1; d <= STAGE_DEPTH3; ++d) gload(kr[d % STAGE_DEPTH3], r0 + d * KT);
     __syncthreads();
 
+    // Append path of one score of the PREVIOUS tile (accumulator set `pv`), dealt out between the MFMAs of the running tile like in
+    // memread_select32_kernel: the fp16 matrix pipe leaves the vector ALU free, so a wave selects tile t - 1 while it multiplies
+    // tile t (with the workgroup barrier keeping the 8 waves in phase, nothing else would overlap the two).
+    uint32_t idx_base = 0u;                           // previous tile's base row + 4h: index of score r = idx_base + 8 (r >> 2) + (r & 3)
+    auto slice = [&](const f32x16_t (&pv)[2], int r) {
+      const float sc = pv[0][r] + pv[1][r];
+      const bool pass = sc > my_tau;
+      if (__ballot(pass)) {                            // wave-uniform: almost never taken once the thresholds have converged
+        if (pass) my_region[my_cnt] = ((uint64_t)__float_as_uint(sc) << 32) | (uint64_t)(idx_base + (uint32_t)(8 * (r >> 2) + (r & 3)));
+        my_cnt += pass ? 1 : 0;
+      }
+    };
     // one tile: tile t + 1 (requested STAGE_DEPTH3 tiles ago) goes to the other LDS buffer (tile t - 1's copy, whose readers passed
     // the barrier of iteration t - 1) and its registers take the request for tile t + 1 + STAGE_DEPTH3; fragments of tile t, 24
-    // MFMAs, selection of its 16 scores per lane; barrier.
-    auto tile_iter = [&](int t, f32x4_t (&krs)[2]) {
+    // MFMAs into `cur` with the selection of tile t - 1 (`pv`) between them; barrier.
+    f32x16_t accA[2], accB[2];
+    auto tile_iter = [&](int t, f32x4_t (&krs)[2], f32x16_t (&cur)[2], const f32x16_t (&pv)[2], auto first) {
+      constexpr bool SELECT = !decltype(first)::value;
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (STAGE_DEPTH3 - 1)) : "memory");
       lds_store(krs, (t + 1) & 1);
       gload(krs, r0 + (t + 1 + STAGE_DEPTH3) * KT);
@@ -957,39 +972,55 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
         fa[2 * ks] = *reinterpret_cast<const f32x4_t *>(arow + 16 * ks);
         fa[2 * ks + 1] = *reinterpret_cast<const f32x4_t *>(arow + 16 * ks + 4);
       }
-      f32x16_t acc[2];
+      idx_base = (uint32_t)(r0 + (t - 1) * KT + 4 * h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { cur[0][r] = 0.f; cur[1][r] = 0.f; }
+#define MIVOS_SB __builtin_amdgcn_sched_barrier(0);
+#define MIVOS_HF(N, A, B) cur[(N) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, A), __builtin_bit_cast(half8_t, B), cur[(N) & 1], 0, 0, 0); MIVOS_SB
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {                 // lo*hi, hi*lo, hi*hi on two alternating accumulators (memread_select32_kernel)
-        acc[(3 * ks) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[2 * ks + 1]), __builtin_bit_cast(half8_t, qf[2 * ks]), acc[(3 * ks) & 1], 0, 0, 0);
-        acc[(3 * ks + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[2 * ks]), __builtin_bit_cast(half8_t, qf[2 * ks + 1]), acc[(3 * ks + 1) & 1], 0, 0, 0);
-        acc[(3 * ks + 2) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[2 * ks]), __builtin_bit_cast(half8_t, qf[2 * ks]), acc[(3 * ks + 2) & 1], 0, 0, 0);
+      for (int ks = 0; ks < 8; ++ks) {
+        if (SELECT && (ks == 0 || ks == 4)) make_room();      // before the appends of scores 0-7 / 8-15
+        MIVOS_HF(3 * ks, fa[2 * ks + 1], qf[2 * ks])           // lo * hi
+        if (SELECT) slice(pv, 2 * ks);
+        MIVOS_SB
+        MIVOS_HF(3 * ks + 1, fa[2 * ks], qf[2 * ks + 1])       // hi * lo
+        if (SELECT) slice(pv, 2 * ks + 1);
+        MIVOS_SB
+        MIVOS_HF(3 * ks + 2, fa[2 * ks], qf[2 * ks])           // hi * hi
       }
-      // (the hazard guard of memread_select32_kernel: MFMA results read by the vector ALU behind a branch)
-      asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
-      const int pb = r0 + t * KT;
-      const uint32_t idx_base = (uint32_t)(pb + 4 * h);
-      const bool tail = pb + KT > r1;                 // only the last tile of a stream can hold rows past the end of the memory
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (r == 0 || r == 8) make_room();
-        float sc = acc[0][r] + acc[1][r];
-        if (tail && pb + 4 * h + 8 * (r >> 2) + (r & 3) >= r1) sc = -INFINITY;
-        const bool pass = sc > my_tau;
-        if (__ballot(pass)) {                          // wave-uniform: almost never taken once the thresholds have converged
-          if (pass) my_region[my_cnt] = ((uint64_t)__float_as_uint(sc) << 32) | (uint64_t)(idx_base + (uint32_t)(8 * (r >> 2) + (r & 3)));
-          my_cnt += pass ? 1 : 0;
-        }
-      }
+#undef MIVOS_HF
+#undef MIVOS_SB
+      // (the hazard guard of memread_select32_kernel: MFMA results read by the vector ALU behind a branch / barrier)
+      asm volatile("s_nop 15" : "+v"(cur[0]), "+v"(cur[1]));
       __syncthreads();
     };
-    for (int t = 0; t < nt; t += STAGE_DEPTH3) {
-      tile_iter(t, kr[1 % STAGE_DEPTH3]);
-      if (t + 1 < nt) tile_iter(t + 1, kr[2 % STAGE_DEPTH3]);
-      if (t + 2 < nt) tile_iter(t + 2, kr[3 % STAGE_DEPTH3]);
-      if (t + 3 < nt) tile_iter(t + 3, kr[0]);
+    static_assert(STAGE_DEPTH3 == 2, "register set of tile t + 1 = (t + 1) % 2 = the accumulator parity below");
+    tile_iter(0, kr[1], accA, accB, std::true_type{});
+    if (nt > 1) tile_iter(1, kr[0], accB, accA, std::false_type{});
+    for (int t = 2; t < nt; t += 2) {
+      tile_iter(t, kr[1], accA, accB, std::false_type{});
+      if (t + 1 < nt) tile_iter(t + 1, kr[0], accB, accA, std::false_type{});
     }
+    // drain the pipeline: select on the last tile (the only one that can hold rows past the end of the memory)
+    auto drain = [&](const f32x16_t (&last)[2]) {
+      const int pb = r0 + (nt - 1) * KT;
+      idx_base = (uint32_t)(pb + 4 * h);
+      f32x16_t masked[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = pb + 4 * h + 8 * (r >> 2) + (r & 3) < r1;
+        masked[0][r] = ok ? last[0][r] : -INFINITY;
+        masked[1][r] = ok ? last[1][r] : -INFINITY;
+      }
+      make_room();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) slice(masked, r);
+      make_room();
+#pragma unroll
+      for (int r = 8; r < 16; ++r) slice(masked, r);
+    };
+    if ((nt - 1) & 1) drain(accB);
+    else drain(accA);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the requests past the end of the segment: their registers are reused
 
     // this segment's candidate lists: for each of the wave's 32 queries between min(n, k) and k + SLACK entries
@@ -1202,7 +1233,9 @@ static std::atomic<long long> g_q256_min{-1};     // ... and from which the 256-
 static long long q256_min() {
   long long v = g_q256_min.load(std::memory_order_relaxed);
   if (v < 0) {
-    v = getenv("MIVOS_MEMREAD_Q256_MIN") ? atoll(getenv("MIVOS_MEMREAD_Q256_MIN")) : (1ll << 60);
+    // measured (profiles/r03g_memread_q256_bench.txt; 1080p, 3 objects): 50 / 100 / 200 frames (408 k / 816 k / 1.63 M positions) 10.36 /
+    // 17.46 / 34.37 ms with 256 queries per workgroup vs 10.53 / 18.74 / 35.11 ms with 128; config 5 end to end 31.8 vs 30.8 frames/s
+    v = getenv("MIVOS_MEMREAD_Q256_MIN") ? atoll(getenv("MIVOS_MEMREAD_Q256_MIN")) : 400000;
     g_q256_min.store(v, std::memory_order_relaxed);
   }
   return v;

@@ -3,7 +3,6 @@
 set +e
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 120 python -m pytest "tests/test_gpu_engine.py::test_480p_propagation_vs_oracle[1]" -m gpu -q -rP 2>&1 | grep -E "clauses|passed|failed" | cut -c1-330
 timeout 240 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "q256" 2>&1 | tail -3 | cut -c1-300
 timeout 240 python -m pytest tests/test_gpu_ops.py -m gpu -q -rP -k "deep_bank" 2>&1 | grep -E "^deep bank|passed|failed|Error" | cut -c1-330
 timeout 120 python scripts/memread_q256_bench.py 2>&1 | tail -4 | tee gpurun_out/r4l_memread_q256_bench.txt

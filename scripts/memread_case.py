@@ -19,5 +19,6 @@ for mode in sys.argv[5:]:
             check(lib.mivos_memory_read_select(keys.data_ptr(), n_mem * 128, q.data_ptr(), K, n_mem, hw, topk, ws.data_ptr(), ws.numel(), st))
         else:
             lib.mivos_memory_read_set_q128_min(0 if mode == "q128" else 1 << 40)
+            lib.mivos_memory_read_set_q256_min(0 if mode == "q256" else 1 << 60)
             check(lib.mivos_memory_read_select_f16x3(ks.data_ptr(), n_mem * 128, q.data_ptr(), K, n_mem, hw, topk, ws.data_ptr(), ws.numel(), st))
     torch.cuda.synchronize()
