@@ -174,7 +174,7 @@ def kernel_rooflines(samples, overhead=0.0, config=3, select_kernel=None):
         ach = flops / secs / 1e12
         f16 = ops_precision() == "f16x3"
         peak = F16X3_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS
-        aff = dict(bound="mfma", kernel="memread_select_kernel<F16> / memread_select256_kernel from 400 k memory positions (error-compensated fp16 MFMA affinity on pre-split keys + streaming top-k)" if f16
+        aff = dict(bound="mfma", kernel="memread_select_kernel<F16> / memread_select256_kernel from 200 k memory positions (error-compensated fp16 MFMA affinity on pre-split keys + streaming top-k)" if f16
                    else "memread_select_kernel (exact fp32 MFMA affinity + streaming top-k)",
                    achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
                    frac_of_f32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
@@ -405,8 +405,8 @@ def main():
     if rank != 0:
         return
     ev_overhead = event_pair_overhead(torch)
-    # the select instantiation that serves this configuration's banks (csrc/memory_read.hip launch_select: the 128-query kernel
-    # from 400 k memory positions, the wave-uniform skip of the append path from 32 k): the PMC traffic record must be ITS
+    # the select instantiation that serves this configuration's banks (csrc/memory_read.hip launch_select: the 256-query kernel
+    # from 200 k memory positions, the wave-uniform skip of the append path from 32 k): the PMC traffic record must be ITS
     sel = None
     if ops.CONV_PRECISION == "f16x3":
         import ctypes

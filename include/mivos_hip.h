@@ -279,7 +279,7 @@ int mivos_memory_read_plan(int n_obj, int64_t n_mem, int n_q, int top_k, int f16
  * kernel (default 400000, or the environment variable MIVOS_MEMREAD_Q128_MIN); returns the previous value, negative = only query. */
 int64_t mivos_memory_read_set_q128_min(int64_t n_mem_min);
 /* ... and the depth from which it uses the 256-queries-per-workgroup kernel (8 waves, candidate regions in global scratch inside the
- * workspace; default 400000 = it takes precedence over the 128-query kernel, environment variable MIVOS_MEMREAD_Q256_MIN). */
+ * workspace; default 200000 = it takes precedence over the 128-query kernel, environment variable MIVOS_MEMREAD_Q256_MIN). */
 int64_t mivos_memory_read_set_q256_min(int64_t n_mem_min);
 int mivos_memory_read_select(const float *keys, int64_t keys_ostride, const float *qk, int n_obj,
                              int64_t n_mem, int n_q, int top_k, void *workspace, int64_t workspace_bytes,

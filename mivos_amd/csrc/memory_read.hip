@@ -146,6 +146,84 @@ __device__ __forceinline__ uint64_t bisect_kth(const uint64_t (&e)[N], int k, in
 // forwards a thread's own earlier load across another lane's store ("nobody in this thread wrote it").
 __device__ __forceinline__ void wave_lds_handoff() { asm volatile("" ::: "memory"); }
 
+// Inclusive prefix sum over the 64 lanes: shifts inside the rows of 16 (DPP row_shr), then the row totals travel with the
+// two row broadcasts (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).
+__device__ __forceinline__ int wave_prefix_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+  return v;
+}
+
+// Same contract as bisect_kth (a prefix p with k <= #(e >= p) <= k + slack, callers guarantee more than k + slack valid
+// entries), found by COUNTING instead of bit by bit: the score words of the valid entries span [mn, mx]; that range is cut into
+// 64 buckets of a power-of-two width (mn = the caller's current threshold, below which there are no candidates), every entry adds one to its bucket's counter in `hist` (64 words of LDS owned by this
+// wave; lane L reads back bucket 63 - L), a prefix sum over the lanes gives "entries in this bucket or above", and the first
+// lane whose sum reaches k names the bucket the cut lies in.  If that leaves more than k + slack survivors the bucket is cut
+// into 64 again (6 more bits of the score per level).  bisect_kth needs one dependent compare / count / branch round per BIT
+// between the highest bit in which the scores differ and the cut - 15 rounds when the pool holds scores of both signs, as it
+// does at the first compaction of every segment; measured 3 160 cycles per compaction at one wave per SIMD,
+// profiles/r02f_memread_cycles.txt - this needs two or three levels.  Exact score ties straddling the cut fall through to the
+// index bisection, like there.
+template <int N>
+__device__ __forceinline__ uint64_t count_kth(const uint64_t (&e)[N], int k, int slack, int &count, uint32_t *hist, int lane, uint32_t lo) {
+  // `lo`: a score word no valid entry lies below (the caller's current threshold: candidates were appended because they beat it)
+  uint32_t h[N];
+  uint32_t mx = 0u;
+#pragma unroll
+  for (int t = 0; t < N; ++t) {
+    h[t] = (uint32_t)(e[t] >> 32);
+    mx = max(mx, h[t]);
+  }
+  mx = wave_umax(mx);
+  const uint32_t range = mx - lo;
+  int shift = range ? 26 - __builtin_clz(range) : 0;       // (range >> shift) < 64
+  if (shift < 0) shift = 0;
+  uint32_t width_m1 = 0xffffffffu;                          // entries of the current range: lo <= h <= lo + width_m1
+  int above = 0;                                            // entries above the current range (all survive)
+  int total;
+  for (;;) {
+    hist[lane] = 0u;
+    wave_lds_handoff();
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+      const uint32_t d = h[t] - lo;
+      if (e[t] != 0ull && h[t] >= lo && d <= width_m1) atomicAdd(&hist[63 - (int)(d >> shift)], 1u);
+    }
+    wave_lds_handoff();
+    const int sum = wave_prefix_sum((int)hist[lane]);       // entries of the range in buckets >= 63 - lane
+    const int need = k - above;                             // >= 1, and the range holds at least that many
+    const unsigned long long m = __ballot(sum >= need);
+    const int l = __builtin_ctzll(m);
+    total = above + __builtin_amdgcn_readlane(sum, l);
+    lo += (uint32_t)(63 - l) << shift;                      // lower edge of the bucket the cut lies in
+    if (total <= k + slack || shift == 0) break;
+    above += l ? __builtin_amdgcn_readlane(sum, l - 1) : 0;
+    width_m1 = (1u << shift) - 1u;
+    shift = shift > 6 ? shift - 6 : 0;
+  }
+  uint64_t prefix = (uint64_t)lo << 32;
+  if (total > k + slack) {                                  // equal scores straddle the cut: decide by index (lower index = larger key)
+#pragma unroll 1
+    for (int b = 31; b >= 0; --b) {
+      const uint64_t trial = prefix | (1ull << b);
+      int c = 0;
+#pragma unroll
+      for (int t = 0; t < N; ++t) c += __popcll(__ballot(e[t] >= trial));
+      if (c >= k) {
+        prefix = trial;
+        total = c;
+        if (c <= k + slack) break;
+      }
+    }
+  }
+  count = total;
+  return prefix;
+}
+
 // Compaction of one query's LDS candidate buffer by the owning wave (all 64 lanes).  The buffer is four lane-private
 // regions of REG entries (region g is appended to by lane (q, g) only, whose VGPR `my_cnt` is its fill level); n0..n3 are
 // the four levels.  More than k + SLACK entries -> between k and k + SLACK survivors, dealt round-robin back to the four
@@ -158,21 +236,26 @@ __device__ __forceinline__ uint64_t raw_to_key(uint64_t raw) {
   return ((uint64_t)f2ord(__uint_as_float((uint32_t)(raw >> 32))) << 32) | (uint64_t)(~(uint32_t)raw);
 }
 
-__device__ __forceinline__ int compact_query(uint64_t *buf, int n0, int n1, int n2, int n3, int k, int lane, float &new_tau) {
+__device__ __forceinline__ int compact_query(uint64_t *buf, int n0, int n1, int n2, int n3, int k, int lane, float &new_tau, uint32_t *hist) {
   constexpr int GS = QW * REG;                         // region g of this query starts at buf + g * GS
   wave_lds_handoff();
+  // unconditional loads (lanes past a region's fill level read stale slots of the same region, lanes 61-63 its last slot) and
+  // selects instead of four exec-masked load + convert blocks: the compaction is a chain of dependent instructions issued by
+  // one wave, so every branch and exec round trip in it is paid in full
+  const int li = lane < REG ? lane : REG - 1;
   uint64_t raw[4], e[4];
-  raw[0] = lane < n0 ? buf[lane] : 0ull;
-  raw[1] = lane < n1 ? buf[GS + lane] : 0ull;
-  raw[2] = lane < n2 ? buf[2 * GS + lane] : 0ull;
-  raw[3] = lane < n3 ? buf[3 * GS + lane] : 0ull;
-  e[0] = lane < n0 ? raw_to_key(raw[0]) : 0ull;
-  e[1] = lane < n1 ? raw_to_key(raw[1]) : 0ull;
-  e[2] = lane < n2 ? raw_to_key(raw[2]) : 0ull;
-  e[3] = lane < n3 ? raw_to_key(raw[3]) : 0ull;
+  raw[0] = buf[li];
+  raw[1] = buf[GS + li];
+  raw[2] = buf[2 * GS + li];
+  raw[3] = buf[3 * GS + li];
+  const uint64_t k0 = raw_to_key(raw[0]), k1 = raw_to_key(raw[1]), k2 = raw_to_key(raw[2]), k3 = raw_to_key(raw[3]);
+  e[0] = lane < n0 ? k0 : 0ull;
+  e[1] = lane < n1 ? k1 : 0ull;
+  e[2] = lane < n2 ? k2 : 0ull;
+  e[3] = lane < n3 ? k3 : 0ull;
   int c = n0 + n1 + n2 + n3;
   uint64_t p = 1ull;                                   // one region nearly full, few entries overall: only rebalance
-  if (c > k + SLACK) p = bisect_kth<4>(e, k, SLACK, c);
+  if (c > k + SLACK) p = count_kth<4>(e, k, SLACK, c, hist, lane, f2ord(new_tau));   // new_tau comes in as the current threshold
   int base = 0;
   const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
@@ -199,6 +282,7 @@ struct SelectArgs {
   int tps;                // tiles per stream
   long long total_tiles;
   int tiles_per_wg, slots, L;
+  int xcd_order;             // 64-query kernel: workgroup b takes chunk (b % 8) * (n / 8) + b / 8 instead of chunk b (see there)
   int *header;               // first 64 bytes of the workspace: the plan this launch used, for the finalize kernel
   int qt;                    // queries per workgroup (QT, QT2 for the 32-queries-per-wave kernel, QT3 for the 8-wave one)
   uint64_t *cand;            // QT3 kernel: global candidate regions, CAND3_PER_WG entries per workgroup
@@ -223,6 +307,7 @@ template <int ABL, bool BR, bool F16>
 __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs a) {
   __shared__ __attribute__((aligned(16))) float ktile[2][KT * KLD];
   __shared__ uint64_t cand[QT * CAP];                 // [wave][g][q][REG]
+  __shared__ uint32_t hist[4][64];                    // bucket counters of a compaction (count_kth), one set per wave
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int jq = lane & 15, g = lane >> 4;
@@ -233,7 +318,13 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
   const int coff = 64 * (g & 1) + 32 * (g >> 1);
   const int lrow = tid >> 3, lc = tid & 7;           // key-tile loader: row tid>>3, float4 columns lc + 8 jj
 
-  long long t_begin = (long long)blockIdx.x * a.tiles_per_wg;
+  // Which chunk of the concatenated streams this workgroup takes.  Workgroup b runs on XCD b % 8 (observed placement, used for
+  // speed only): with chunk = b, the chunks that walk the SAME keys (every tps / tiles_per_wg-th one: the same part of the bank
+  // for the next 64 queries) sit on different XCDs and every one of them pulls its keys through the fabric (480p, 5 objects:
+  // 930 MB per launch for a 29 MB bank, profiles/r02c_pmc_traffic.json).  With the XCD-major order an XCD runs n / 8
+  // CONSECUTIVE chunks - a dozen query tiles of one object, whose windows over the bank overlap - out of its own L2.
+  const int chunk = a.xcd_order ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  long long t_begin = (long long)chunk * a.tiles_per_wg;
   const long long t_end = (t_begin + a.tiles_per_wg < a.total_tiles) ? t_begin + a.tiles_per_wg : a.total_tiles;
   const bool prof = a.dbg && blockIdx.x == 0;       // profiling builds only (MIVOS_MEMREAD_DBG)
   const unsigned long long clk0 = prof ? __builtin_readcyclecounter() : 0ull;
@@ -247,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
     if (seg_hi > a.tps) seg_hi = a.tps;
     const int nt = seg_hi - seg_lo;
     const int obj = stream / a.n_qtiles, qtile = stream - obj * a.n_qtiles;
-    const int slot = (int)blockIdx.x - (int)(((long long)stream * a.tps) / a.tiles_per_wg);
+    const int slot = chunk - (int)(((long long)stream * a.tps) / a.tiles_per_wg);
     // memory positions are 32-bit (n_mem < 2^31 is checked on the host)
     const int r0 = seg_lo * KT;
     const int r1 = ((long long)seg_hi * KT < a.n_mem) ? seg_hi * KT : (int)a.n_mem;
@@ -324,26 +415,27 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
     // is one basic block and the slices issue in the shadow of the matrix pipe.
     // Lane (q, g) appends to ITS region of query q's buffer at its private fill level: no atomic, no LDS round trip.
     uint64_t *const my_region = cand + ((wave * 4 + g) * QW + jq) * REG;
-    int my_cnt = 0;
-    // Append path, per score register: ONE vector compare, the index (one subtract from a per-tile base), the LDS address
-    // (fill level * 8 + region), a store executed by the passing lanes only (exec := the compare's mask around one
-    // ds_write2_b32; no branch) and an add-with-carry of the mask into the fill level.  Measured (MIVOS_ABL=2..4): a wave's
-    // VALU / LDS-store instructions cost their full issue time next to its own fp32 MFMAs - nothing here is hidden - so the
+    // Append path, per score register: ONE vector compare, the index (one add to a per-tile base), and - executed by the
+    // passing lanes only, exec := the compare's mask, no branch - the advance of the lane's write pointer and one
+    // ds_write2_b32 through it.  The fill level IS that pointer (my_top = LDS byte address of the newest entry; the level is
+    // only needed as a number when a compaction runs), so there is no address arithmetic and no add-with-carry per score:
+    // 3 vector + 1 LDS + 2 scalar instructions (5 + 1 + 2 with a counter).  Measured (MIVOS_ABL=2..4): a wave's VALU /
+    // LDS-store instructions cost their full issue time next to its own fp32 MFMAs - nothing here is hidden - so the
     // instruction count is the cost; entries stay raw {score bits, index}, the orderable key is built at compaction time.
     const uint32_t region_lds = (uint32_t)(size_t)my_region;     // LDS byte address of this lane's region
+    uint32_t my_top = region_lds - 8u;                // no entry yet
+    auto fill_level = [&]() { return (int)((my_top + 8u - region_lds) >> 3); };
     bool s_pass;
     uint32_t idx_base = 0u;                           // pb + 4g: index of (sub, r) = idx_base + 16 sub + r
     auto slice_a = [&](int i) { s_pass = ((i < 4) ? p0[i & 3] : p1[i & 3]) > my_tau; };
     auto slice_b = [&](int i) {
       const unsigned long long m = __ballot(s_pass);
       if (BR && m == 0ull) return;
-      const uint32_t addr = region_lds + 8u * (uint32_t)my_cnt;
       const uint32_t idx = idx_base + (uint32_t)(16 * (i >> 2) + (i & 3));
       const uint32_t bits = __float_as_uint((i < 4) ? p0[i & 3] : p1[i & 3]);
       unsigned long long saved;
-      asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write2_b32 %2, %3, %4 offset1:1\n\ts_mov_b64 exec, %0"
-                   : "=&s"(saved) : "s"(m), "v"(addr), "v"(idx), "v"(bits) : "memory");
-      my_cnt += s_pass ? 1 : 0;
+      asm volatile("s_and_saveexec_b64 %0, %2\n\tv_add_u32_e32 %1, 8, %1\n\tds_write2_b32 %1, %3, %4 offset1:1\n\ts_mov_b64 exec, %0"
+                   : "=&s"(saved), "+v"(my_top) : "s"(m), "v"(idx), "v"(bits) : "memory");
     };
     // latch the scores of tile t for the selection that runs during tile t+1; only the last tile of a stream can hold rows
     // past the end of the memory (scores of whatever row was loaded instead): those become -inf here
@@ -361,16 +453,18 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
     };
     // compaction of query `ql` (0..15) of this wave: fill levels come from the four owner lanes, go back to them
     auto compact_one = [&](int ql, bool force) {
+      const int my_cnt = fill_level();
       const int n0 = __builtin_amdgcn_readlane(my_cnt, ql), n1 = __builtin_amdgcn_readlane(my_cnt, ql + 16);
       const int n2 = __builtin_amdgcn_readlane(my_cnt, ql + 32), n3 = __builtin_amdgcn_readlane(my_cnt, ql + 48);
       if (force && n0 + n1 + n2 + n3 <= a.top_k + SLACK) return;   // end of a segment: the list takes the regions as they are
-      float nt_tau = my_tau;                                       // (unchanged when nothing is dropped)
-      const int c = compact_query(cand + (wave * 4 * QW + ql) * REG, n0, n1, n2, n3, a.top_k, lane, nt_tau);
-      if (jq == ql) { my_cnt = (c - g + 3) >> 2; my_tau = nt_tau; }
+      // query ql's threshold, wave-uniform (it stays when nothing is dropped); compact_query also takes it as the lower bound
+      float nt_tau = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_tau), ql));
+      const int c = compact_query(cand + (wave * 4 * QW + ql) * REG, n0, n1, n2, n3, a.top_k, lane, nt_tau, hist[wave]);
+      if (jq == ql) { my_top = region_lds - 8u + 8u * (uint32_t)((c - g + 3) >> 2); my_tau = nt_tau; }
     };
     auto make_room = [&]() {
       // before the (up to 8 per lane) appends of a tile: compact every buffer of this wave with a region that might overflow
-      const unsigned long long full = __ballot(my_cnt > REG_TRIGGER);
+      const unsigned long long full = __ballot((int)(my_top - region_lds) > 8 * REG_TRIGGER - 8);
       unsigned need = (unsigned)((full | (full >> 16) | (full >> 32) | (full >> 48)) & 0xffffull);
       if (need) {
         const unsigned long long c0 = prof ? __builtin_readcyclecounter() : 0ull;
@@ -503,6 +597,7 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
     for (int ql = 0; ql < QW; ++ql) {
       compact_one(ql, true);
       wave_lds_handoff();
+      const int my_cnt = fill_level();
       const int n0 = __builtin_amdgcn_readlane(my_cnt, ql), n1 = __builtin_amdgcn_readlane(my_cnt, ql + 16);
       const int n2 = __builtin_amdgcn_readlane(my_cnt, ql + 32), n3 = __builtin_amdgcn_readlane(my_cnt, ql + 48);
       const int s = wave * QW + ql;
@@ -520,7 +615,7 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
   }
   if (prof && tid == 0) {
     a.dbg[0] = __builtin_readcyclecounter() - clk0;
-    a.dbg[1] = (unsigned long long)(t_end - (long long)blockIdx.x * a.tiles_per_wg);
+    a.dbg[1] = (unsigned long long)(t_end - (long long)chunk * a.tiles_per_wg);
     a.dbg[2] = clk_room; a.dbg[3] = n_compact; a.dbg[4] = clk_final; a.dbg[5] = clk_pro;
   }
 }
@@ -816,27 +911,36 @@ __global__ __launch_bounds__(256, 1) void memread_select32_kernel(const SelectAr
 // once the thresholds have converged (a few hundred positions into a stream of 10^5 - 10^6) almost no score passes, the
 // append is a rare exec-masked global store and a compaction a rare round trip to L2.  LDS then only holds the two key tiles.
 //   8 waves x 32 queries per workgroup (two waves per SIMD: one fills the matrix pipe while the other reads its fragments and
-//   selects); 256 VGPRs per wave, so one fragment set (read at the start of a tile), two accumulator pairs (tile t - 1 is selected
-//   between the MFMAs of tile t, like in memread_select32_kernel) and two key tiles in flight; tile t + 1 is written to the other LDS
-//   buffer during tile t (explicit vmcnt as above), one barrier per tile.
+//   selects); 256 VGPRs per wave, so one fragment set (read at the start of a tile), two accumulator sets (tile t - 1 is selected
+//   between the MFMAs of tile t, like in memread_select32_kernel; one chain of 24 MFMAs per tile) and four key tiles in flight
+//   (explicit vmcnt as above); LDS is a ring of eight tiles and the workgroup synchronises once per four tiles (see tile_iter).
 //   A wave's own global stores are ordered before its later loads by a workgroup-scope fence (same CU, same L1) and the
 //   reads bypass L1 (agent-scope loads) for good measure.  The explicit `s_waitcnt vmcnt(N)` of the key pipeline stays
 //   correct with stores in flight: they only add to the count, and the count cannot fall to N before the oldest loads landed.
-constexpr int NW3 = 8, QT3 = 256, REG3 = 61, REG3_TRIGGER = REG3 - 1 - 8, STAGE_DEPTH3 = 2;   // (2 key tiles in flight: 256 VGPRs per wave)
+constexpr int NW3 = 8, QT3 = 256, REG3 = 61, REG3_TRIGGER = REG3 - 1 - 16;   // (room for a whole tile's 16 appends per lane is made once per tile)
+constexpr int GROUP3 = 4, NBUF3 = 2 * GROUP3;   // key tiles per barrier; LDS ring of two groups (LDS holds nothing else here: 132 KB)
 constexpr long long CAND3_PER_WG = (long long)NW3 * 2 * 32 * REG3;      // candidate entries (8 bytes each) per workgroup
 
-__device__ __forceinline__ uint64_t gload_entry(const uint64_t *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Two candidate entries read back from the global scratch (agent-scope loads: past the CU's L1).  Inline assembly ON PURPOSE:
+// a load the compiler knows of makes it guard every later write of the destination registers - which it reuses for the
+// accumulators - with an `s_waitcnt vmcnt(0)` at the join behind the (rarely taken) compaction branch, i.e. at the first MFMA
+// of EVERY tile, where that wait also drains the key requests just issued (the tile pipeline then runs at one memory latency
+// per tile: the first two versions of this kernel, 17 - 18 ms at 1080p T = 100).  These requests are invisible to the compiler
+// like the key requests; the wait is written out and tied to the results.
+__device__ __forceinline__ void gload_entries(const uint64_t *p0, const uint64_t *p1, uint64_t &v0, uint64_t &v1) {
+  asm volatile("global_load_dwordx2 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
 }
 
 __device__ __forceinline__ int compact_query_g(uint64_t *buf, int n0, int n1, int k, int lane, float &new_tau) {
   constexpr int GS = 32 * REG3;                        // region h of this query starts at buf + h * GS
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  const int li = lane < REG3 ? lane : REG3 - 1;       // unconditional loads (stale slots of the same region past its fill level)
   uint64_t raw[2], e[2];
-  raw[0] = lane < n0 ? gload_entry(buf + lane) : 0ull;
-  raw[1] = lane < n1 ? gload_entry(buf + GS + lane) : 0ull;
-  e[0] = lane < n0 ? raw_to_key(raw[0]) : 0ull;
-  e[1] = lane < n1 ? raw_to_key(raw[1]) : 0ull;
+  gload_entries(buf + li, buf + GS + li, raw[0], raw[1]);
+  const uint64_t k0 = raw_to_key(raw[0]), k1 = raw_to_key(raw[1]);
+  e[0] = lane < n0 ? k0 : 0ull;
+  e[1] = lane < n1 ? k1 : 0ull;
   int c = n0 + n1;
   uint64_t p = 1ull;                                   // one region nearly full, few entries overall: only rebalance
   if (c > k + SLACK) p = bisect_kth<2>(e, k, SLACK, c);
@@ -856,7 +960,7 @@ __device__ __forceinline__ int compact_query_g(uint64_t *buf, int n0, int n1, in
 }
 
 __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectArgs a) {
-  __shared__ __attribute__((aligned(16))) float ktile[2][KT * KLD];
+  __shared__ __attribute__((aligned(16))) float ktile[NBUF3][KT * KLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int qslot = wave * 32 + j;
@@ -905,7 +1009,7 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
       for (int x = 0; x < 16; ++x) asm volatile("" : "+v"(qf[x]));      // finished before the key requests go out
     }
 
-    f32x4_t kr[STAGE_DEPTH3][2];
+    f32x4_t kr[GROUP3][2];
     auto gload = [&](f32x4_t (&krs)[2], int kb) {
       const int m = kb + lrow;                        // rows past the segment's end: its first row instead (never selected)
       const f32x4_t *src = reinterpret_cast<const f32x4_t *>(kbase + (long long)(m < r1 ? m : r0) * CK) + lc;
@@ -936,36 +1040,53 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
       }
     };
 
-    // prologue: tile 0 into LDS buffer 0, tiles 1 .. STAGE_DEPTH3 requested (tile i -> register set i % STAGE_DEPTH3)
-    gload(kr[0], r0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_store(kr[0], 0);
+    // prologue: the first group of tiles into LDS slots 0 .. GROUP3 - 1, the second group requested (tile t -> register set t % GROUP3)
 #pragma unroll
-    for (int d = 1; d <= STAGE_DEPTH3; ++d) gload(kr[d % STAGE_DEPTH3], r0 + d * KT);
+    for (int d = 0; d < GROUP3; ++d) gload(kr[d], r0 + d * KT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int d = 0; d < GROUP3; ++d) lds_store(kr[d], d);
+#pragma unroll
+    for (int d = 0; d < GROUP3; ++d) gload(kr[d], r0 + (GROUP3 + d) * KT);
     __syncthreads();
 
     // Append path of one score of the PREVIOUS tile (accumulator set `pv`), dealt out between the MFMAs of the running tile like in
     // memread_select32_kernel: the fp16 matrix pipe leaves the vector ALU free, so a wave selects tile t - 1 while it multiplies
     // tile t (with the workgroup barrier keeping the 8 waves in phase, nothing else would overlap the two).
     uint32_t idx_base = 0u;                           // previous tile's base row + 4h: index of score r = idx_base + 8 (r >> 2) + (r & 3)
-    auto slice = [&](const f32x16_t (&pv)[2], int r) {
-      const float sc = pv[0][r] + pv[1][r];
-      const bool pass = sc > my_tau;
-      if (__ballot(pass)) {                            // wave-uniform: almost never taken once the thresholds have converged
-        if (pass) my_region[my_cnt] = ((uint64_t)__float_as_uint(sc) << 32) | (uint64_t)(idx_base + (uint32_t)(8 * (r >> 2) + (r & 3)));
-        my_cnt += pass ? 1 : 0;
+    // Scores are tested FOUR at a time: once the thresholds have converged (a few hundred positions into a stream of 10^5 - 10^6)
+    // no score passes in almost every wave tile, so the common path per four scores is max3 + max + compare + one wave-uniform
+    // branch (3 vector instructions instead of 8: the three products of a k-step go into ONE accumulator chain - measured, 1, 2
+    // or 3 chains issue alike, DESIGN "What bounds it now" - so there is no add of two partial sums either); the four scores are
+    // looked at one by one only behind that branch.
+    auto slice4 = [&](const f32x16_t &pv, int g4) {
+      float m4;                                        // (fmaxf would canonicalise every MFMA result first: two more instructions)
+      asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32_e32 %0, %0, %4" : "=&v"(m4) : "v"(pv[4 * g4]), "v"(pv[4 * g4 + 1]), "v"(pv[4 * g4 + 2]), "v"(pv[4 * g4 + 3]));
+      if (__builtin_expect(__ballot(m4 > my_tau) != 0ull, 0)) {
+#pragma unroll
+        for (int r = 4 * g4; r < 4 * g4 + 4; ++r) {
+          const float sc = pv[r];
+          const bool pass = sc > my_tau;
+          if (pass) my_region[my_cnt] = ((uint64_t)__float_as_uint(sc) << 32) | (uint64_t)(idx_base + (uint32_t)(8 * (r >> 2) + (r & 3)));
+          my_cnt += pass ? 1 : 0;
+        }
       }
     };
-    // one tile: tile t + 1 (requested STAGE_DEPTH3 tiles ago) goes to the other LDS buffer (tile t - 1's copy, whose readers passed
-    // the barrier of iteration t - 1) and its registers take the request for tile t + 1 + STAGE_DEPTH3; fragments of tile t, 24
-    // MFMAs into `cur` with the selection of tile t - 1 (`pv`) between them; barrier.
-    f32x16_t accA[2], accB[2];
-    auto tile_iter = [&](int t, f32x4_t (&krs)[2], f32x16_t (&cur)[2], const f32x16_t (&pv)[2], auto first) {
+    // One tile.  The workgroup synchronises once per GROUP of four tiles, not per tile: LDS is a ring of two groups, during group g
+    // every wave writes its rows of the tiles of group g + 1 (requested a group ago; their registers take the requests for group
+    // g + 2) into the other half of the ring, and the barrier at the end of the group is the only point where "those tiles are
+    // complete" and "nobody reads this half any more" have to hold.  Inside a group the eight waves drift apart, so that one
+    // wave's fragment reads (16 ds_read_b128 at the start of a tile; 128 KB per tile for the workgroup = 1 000 LDS cycles) overlap
+    // the other waves' MFMAs (1 536 matrix-pipe cycles per tile and SIMD) instead of alternating with them in lockstep, and a
+    // wave that has to compact a query stalls the others only if it is still behind at the end of the group.
+    // Tile t: its fragments, 24 MFMAs into `cur` with the selection of tile t - 1 (`pv`) between them.
+    f32x16_t accA, accB;
+    auto tile_iter = [&](int t, f32x4_t (&krs)[2], f32x16_t &cur, const f32x16_t &pv, auto first) {
       constexpr bool SELECT = !decltype(first)::value;
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (STAGE_DEPTH3 - 1)) : "memory");
-      lds_store(krs, (t + 1) & 1);
-      gload(krs, r0 + (t + 1 + STAGE_DEPTH3) * KT);
-      const float *arow = &ktile[t & 1][j * KLD + 8 * h];
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (GROUP3 - 1)) : "memory");     // tile t + GROUP3 has landed (requests complete in order)
+      lds_store(krs, (t + GROUP3) & (NBUF3 - 1));
+      gload(krs, r0 + (t + 2 * GROUP3) * KT);
+      const float *arow = &ktile[t & (NBUF3 - 1)][j * KLD + 8 * h];
       f32x4_t fa[16];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
@@ -974,50 +1095,45 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
       }
       idx_base = (uint32_t)(r0 + (t - 1) * KT + 4 * h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { cur[0][r] = 0.f; cur[1][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) cur[r] = 0.f;
+      if (SELECT) make_room();                                 // before the (up to 16 per lane) appends of the previous tile's scores
 #define MIVOS_SB __builtin_amdgcn_sched_barrier(0);
-#define MIVOS_HF(N, A, B) cur[(N) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, A), __builtin_bit_cast(half8_t, B), cur[(N) & 1], 0, 0, 0); MIVOS_SB
+#define MIVOS_HF(A, B) cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, A), __builtin_bit_cast(half8_t, B), cur, 0, 0, 0); MIVOS_SB
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        if (SELECT && (ks == 0 || ks == 4)) make_room();      // before the appends of scores 0-7 / 8-15
-        MIVOS_HF(3 * ks, fa[2 * ks + 1], qf[2 * ks])           // lo * hi
-        if (SELECT) slice(pv, 2 * ks);
+        MIVOS_HF(fa[2 * ks + 1], qf[2 * ks])                   // lo * hi
+        if (SELECT && (ks & 1) == 0) slice4(pv, ks >> 1);      // scores 4 (ks / 2) .. + 3 of the previous tile
         MIVOS_SB
-        MIVOS_HF(3 * ks + 1, fa[2 * ks], qf[2 * ks + 1])       // hi * lo
-        if (SELECT) slice(pv, 2 * ks + 1);
-        MIVOS_SB
-        MIVOS_HF(3 * ks + 2, fa[2 * ks], qf[2 * ks])           // hi * hi
+        MIVOS_HF(fa[2 * ks], qf[2 * ks + 1])                   // hi * lo
+        MIVOS_HF(fa[2 * ks], qf[2 * ks])                       // hi * hi
       }
 #undef MIVOS_HF
 #undef MIVOS_SB
       // (the hazard guard of memread_select32_kernel: MFMA results read by the vector ALU behind a branch / barrier)
-      asm volatile("s_nop 15" : "+v"(cur[0]), "+v"(cur[1]));
-      __syncthreads();
+      asm volatile("s_nop 15" : "+v"(cur));
+      if (((t + 1) & (GROUP3 - 1)) == 0) __syncthreads();
     };
-    static_assert(STAGE_DEPTH3 == 2, "register set of tile t + 1 = (t + 1) % 2 = the accumulator parity below");
-    tile_iter(0, kr[1], accA, accB, std::true_type{});
-    if (nt > 1) tile_iter(1, kr[0], accB, accA, std::false_type{});
-    for (int t = 2; t < nt; t += 2) {
-      tile_iter(t, kr[1], accA, accB, std::false_type{});
-      if (t + 1 < nt) tile_iter(t + 1, kr[0], accB, accA, std::false_type{});
+    static_assert(GROUP3 == 4, "the tile loop is written out for four register sets");
+    tile_iter(0, kr[0], accA, accB, std::true_type{});
+    if (nt > 1) tile_iter(1, kr[1], accB, accA, std::false_type{});
+    if (nt > 2) tile_iter(2, kr[2], accA, accB, std::false_type{});
+    if (nt > 3) tile_iter(3, kr[3], accB, accA, std::false_type{});
+    for (int t = 4; t < nt; t += 4) {
+      tile_iter(t, kr[0], accA, accB, std::false_type{});
+      if (t + 1 < nt) tile_iter(t + 1, kr[1], accB, accA, std::false_type{});
+      if (t + 2 < nt) tile_iter(t + 2, kr[2], accA, accB, std::false_type{});
+      if (t + 3 < nt) tile_iter(t + 3, kr[3], accB, accA, std::false_type{});
     }
     // drain the pipeline: select on the last tile (the only one that can hold rows past the end of the memory)
-    auto drain = [&](const f32x16_t (&last)[2]) {
+    auto drain = [&](const f32x16_t &last) {
       const int pb = r0 + (nt - 1) * KT;
       idx_base = (uint32_t)(pb + 4 * h);
-      f32x16_t masked[2];
+      f32x16_t masked;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok = pb + 4 * h + 8 * (r >> 2) + (r & 3) < r1;
-        masked[0][r] = ok ? last[0][r] : -INFINITY;
-        masked[1][r] = ok ? last[1][r] : -INFINITY;
-      }
+      for (int r = 0; r < 16; ++r) masked[r] = (pb + 4 * h + 8 * (r >> 2) + (r & 3) < r1) ? last[r] : -INFINITY;
       make_room();
 #pragma unroll
-      for (int r = 0; r < 8; ++r) slice(masked, r);
-      make_room();
-#pragma unroll
-      for (int r = 8; r < 16; ++r) slice(masked, r);
+      for (int g4 = 0; g4 < 4; ++g4) slice4(masked, g4);
     };
     if ((nt - 1) & 1) drain(accB);
     else drain(accA);
@@ -1031,8 +1147,11 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
       const int s = wave * 32 + ql;
       const uint64_t *src = wave_regions + ql * REG3;               // region h at src + h * 32 * REG3
       uint64_t *dst = a.lists + (((long long)stream * a.slots + slot) * QT3 + s) * a.L;
-      if (lane < n0) dst[lane] = raw_to_key(gload_entry(src + lane));
-      if (lane < n1) dst[n0 + lane] = raw_to_key(gload_entry(src + 32 * REG3 + lane));
+      const int li = lane < REG3 ? lane : REG3 - 1;
+      uint64_t e0, e1;
+      gload_entries(src + li, src + 32 * REG3 + li, e0, e1);
+      if (lane < n0) dst[lane] = raw_to_key(e0);
+      if (lane < n1) dst[n0 + lane] = raw_to_key(e1);
       for (int i = n0 + n1 + lane; i < a.L; i += 64) dst[i] = 0ull;
     }
     t_begin += nt;
@@ -1233,9 +1352,10 @@ static std::atomic<long long> g_q256_min{-1};     // ... and from which the 256-
 static long long q256_min() {
   long long v = g_q256_min.load(std::memory_order_relaxed);
   if (v < 0) {
-    // measured (profiles/r03g_memread_q256_bench.txt; 1080p, 3 objects): 50 / 100 / 200 frames (408 k / 816 k / 1.63 M positions) 10.36 /
-    // 17.46 / 34.37 ms with 256 queries per workgroup vs 10.53 / 18.74 / 35.11 ms with 128; config 5 end to end 31.8 vs 30.8 frames/s
-    v = getenv("MIVOS_MEMREAD_Q256_MIN") ? atoll(getenv("MIVOS_MEMREAD_Q256_MIN")) : 400000;
+    // measured (profiles/r03h_memread_depth_sweep.txt; ms per launch with 64 / 128 / 256 queries per workgroup): 1080p, 3 objects,
+    // 20 frames (163 k positions) 4.69 / 4.94 / 4.70, 30 frames 6.77 / 6.64 / 6.25, 50 frames 10.9 / 10.0 / 9.24, 200 frames
+    // 41.8 / 34.5 / 28.3; 480p, 5 objects, 100 frames (162 k positions) 2.16 / 2.47 / 2.51
+    v = getenv("MIVOS_MEMREAD_Q256_MIN") ? atoll(getenv("MIVOS_MEMREAD_Q256_MIN")) : 200000;
     g_q256_min.store(v, std::memory_order_relaxed);
   }
   return v;
@@ -1341,6 +1461,8 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
   a.lists = (uint64_t *)((char *)workspace + HEADER_BYTES); a.n_mem = n_mem; a.n_q = n_q;
   a.top_k = top_k; a.n_qtiles = pl.n_qtiles; a.tps = pl.tps; a.total_tiles = pl.total; a.tiles_per_wg = pl.tiles_per_wg;
   a.slots = pl.slots; a.L = pl.L; a.qt = qt;
+  static const int xcd_order = getenv("MIVOS_MEMREAD_XCD_ORDER") ? atoi(getenv("MIVOS_MEMREAD_XCD_ORDER")) : 1;   // tuning only
+  a.xcd_order = (xcd_order && qt == QT && pl.n_wg % 8 == 0 && pl.n_wg >= 16) ? 1 : 0;
   a.cand = (uint64_t *)((char *)workspace + HEADER_BYTES + max_lists_bytes(n_obj, n_mem, n_q, top_k));
   static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;          // profiling only
   static const int dbg = getenv("MIVOS_MEMREAD_DBG") ? atoi(getenv("MIVOS_MEMREAD_DBG")) : 0;   // profiling only: prints cycles per tile

@@ -496,14 +496,15 @@ def test_memory_read_vs_oracle(T, h, w, K, top_k, mem_precision):
         ref_sets = torch.sort(ridx[:top_k].t(), dim=1)[0]
         same = (got_sets == ref_sets).all(dim=1)
         assert bool(same[clear].all())
-        assert torch.equal(idx[o][:, 0].long()[clear], ridx[0][clear])          # best first
+        clear1 = clear & ((vals[0] - vals[1]) > 1e-5)             # best first, where ranks 1 and 2 do not tie within fp32 rounding
+        assert torch.equal(idx[o][:, 0].long()[clear1], ridx[0][clear1]) and int(clear1.sum()) >= int(clear.sum()) - max(2, clear.numel() // 100)
         assert float((wgt[o].sum(1) - 1).abs().max()) < 1e-5
 
 
 @pytest.mark.parametrize("frames,scale", [(50, 1.0), (150, 1.7)])
 def test_memory_read_deep_bank_1080p_vs_chunked_oracle(frames, scale):
     """BASELINE config 5's regime (1080x1920 -> 68x120 = 8160 positions per frame, K = 3, top-50, banks of 8160 x {50, 150}
-    = 408 k / 1.22 M positions per object) with the DEFAULT kernel selection (memread_select32_kernel from 400 k positions)
+    = 408 k / 1.22 M positions per object) with the DEFAULT kernel selection (memread_select256_kernel from 200 k positions)
     and InferenceCore's bank geometry: `bank[:, :n]` views of pre-allocated [K, slots, h, w, C] banks whose object strides
     exceed 2^31 BYTES for keys, split keys and values.  Checker: oracle/chunked_read.py (the reference's affinity -> topk ->
     softmax -> readout, 256 queries at a time, in fp64 and in fp32, as plain torch on this GPU - the materialised affinity
@@ -559,7 +560,11 @@ def test_memory_read_deep_bank_1080p_vs_chunked_oracle(frames, scale):
               f"index sets equal on {int(same[clear].sum())} of {int(clear.sum())} clear queries")
         assert int((~clear).sum()) <= clear.numel() // 100
         assert bool(same[clear].all())
-        assert torch.equal(o_idx[..., 0].long()[clear], r64["idx"][..., 0][clear])                 # best first
+        # best first - where the fp64 scores of rank 1 and rank 2 are further apart than fp32 rounding of a 128-term sum
+        # (the order INSIDE the selected set moves neither the set nor, beyond 1e-6, the weights)
+        top_clear = clear & ((r64["weights"][..., 0] / r64["weights"][..., 1]).log() > 1e-5)
+        assert int(top_clear.sum()) > 0.99 * clear.numel()
+        assert torch.equal(o_idx[..., 0].long()[top_clear], r64["idx"][..., 0][top_clear])
         assert float(d64[clear].max()) < 2e-4 and float(d32[clear].max()) < 2e-4
         assert float(d64.max()) < 0.5                                             # an unclear query swaps ONE neighbour of weight ~1/k
     assert float((wgt.sum(2) - 1).abs().max()) < 1e-5

@@ -212,7 +212,7 @@ def test_memory_read_work_partition(n_obj, n_mem, n_q, top_k, f16x3):
     out = (C.c_int32 * 7)()
     assert lib.mivos_memory_read_plan(n_obj, n_mem, n_q, top_k, f16x3, out) == 0
     n_wg, per_wg, slots, tps, streams, L, qt = list(out)
-    assert qt == (256 if f16x3 and n_mem >= 400000 else 64)         # 8 waves x 32 queries per workgroup for long memories (fp16 kernel)
+    assert qt == (256 if f16x3 and n_mem >= 200000 else 64)         # 8 waves x 32 queries per workgroup for long memories (fp16 kernel)
     assert streams == n_obj * -(-n_q // qt) and tps == -(-n_mem // 32) and L == top_k + 16
     total = streams * tps
     assert 1 <= n_wg <= 256 and (n_wg - 1) * per_wg < total <= n_wg * per_wg and slots <= 12
