@@ -282,7 +282,6 @@ struct SelectArgs {
   int tps;                // tiles per stream
   long long total_tiles;
   int tiles_per_wg, slots, L;
-  int xcd_order;             // 64-query kernel: workgroup b takes chunk (b % 8) * (n / 8) + b / 8 instead of chunk b (see there)
   int *header;               // first 64 bytes of the workspace: the plan this launch used, for the finalize kernel
   int qt;                    // queries per workgroup (QT, QT2 for the 32-queries-per-wave kernel, QT3 for the 8-wave one)
   uint64_t *cand;            // QT3 kernel: global candidate regions, CAND3_PER_WG entries per workgroup
@@ -318,12 +317,10 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
   const int coff = 64 * (g & 1) + 32 * (g >> 1);
   const int lrow = tid >> 3, lc = tid & 7;           // key-tile loader: row tid>>3, float4 columns lc + 8 jj
 
-  // Which chunk of the concatenated streams this workgroup takes.  Workgroup b runs on XCD b % 8 (observed placement, used for
-  // speed only): with chunk = b, the chunks that walk the SAME keys (every tps / tiles_per_wg-th one: the same part of the bank
-  // for the next 64 queries) sit on different XCDs and every one of them pulls its keys through the fabric (480p, 5 objects:
-  // 930 MB per launch for a 29 MB bank, profiles/r02c_pmc_traffic.json).  With the XCD-major order an XCD runs n / 8
-  // CONSECUTIVE chunks - a dozen query tiles of one object, whose windows over the bank overlap - out of its own L2.
-  const int chunk = a.xcd_order ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  // (Measured and dropped, round 3: dealing the chunks XCD-major - workgroup b, which runs on XCD b % 8, takes chunk
+  // (b % 8) * (n / 8) + b / 8, so that an XCD's workgroups walk overlapping parts of one object's bank - changes nothing at
+  // 480p: 283.4 vs 283.9 us, profiles/r03h_memread_microbench.txt.  The kernel is not waiting for keys there.)
+  const int chunk = (int)blockIdx.x;
   long long t_begin = (long long)chunk * a.tiles_per_wg;
   const long long t_end = (t_begin + a.tiles_per_wg < a.total_tiles) ? t_begin + a.tiles_per_wg : a.total_tiles;
   const bool prof = a.dbg && blockIdx.x == 0;       // profiling builds only (MIVOS_MEMREAD_DBG)
@@ -1114,7 +1111,7 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
       if (((t + 1) & (GROUP3 - 1)) == 0) __syncthreads();
     };
     static_assert(GROUP3 == 4, "the tile loop is written out for four register sets");
-    tile_iter(0, kr[0], accA, accB, std::true_type{});
+    tile_iter(0, kr[0], accA, accA, std::true_type{});            // (no previous tile to select on: `pv` is not read)
     if (nt > 1) tile_iter(1, kr[1], accB, accA, std::false_type{});
     if (nt > 2) tile_iter(2, kr[2], accA, accB, std::false_type{});
     if (nt > 3) tile_iter(3, kr[3], accB, accA, std::false_type{});
@@ -1461,8 +1458,6 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
   a.lists = (uint64_t *)((char *)workspace + HEADER_BYTES); a.n_mem = n_mem; a.n_q = n_q;
   a.top_k = top_k; a.n_qtiles = pl.n_qtiles; a.tps = pl.tps; a.total_tiles = pl.total; a.tiles_per_wg = pl.tiles_per_wg;
   a.slots = pl.slots; a.L = pl.L; a.qt = qt;
-  static const int xcd_order = getenv("MIVOS_MEMREAD_XCD_ORDER") ? atoi(getenv("MIVOS_MEMREAD_XCD_ORDER")) : 1;   // tuning only
-  a.xcd_order = (xcd_order && qt == QT && pl.n_wg % 8 == 0 && pl.n_wg >= 16) ? 1 : 0;
   a.cand = (uint64_t *)((char *)workspace + HEADER_BYTES + max_lists_bytes(n_obj, n_mem, n_q, top_k));
   static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;          // profiling only
   static const int dbg = getenv("MIVOS_MEMREAD_DBG") ? atoi(getenv("MIVOS_MEMREAD_DBG")) : 0;   // profiling only: prints cycles per tile
