@@ -33,7 +33,9 @@
 //   in ascending memory index - the order in which the reference's dense bmm meets its non-zeros.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 #include "conv_common.h"
 
@@ -1393,14 +1395,38 @@ static void launch_finalize_n(void *workspace, const float *values, int64_t valu
                      (long long)values_ostride, out, (long long)out_ostride, (long long)out_pstride, idx_out, w_out, n_q, top_k, sh);
 }
 
-// The kernel reads the plan from the workspace header; the host only picks how many merged candidates a lane may hold, for
-// the larger of the plans a select call could have used with these sizes.
+// Which plan the last select launch on a workspace used (host-side mirror of the header it leaves in the workspace, which the
+// host cannot read without a synchronisation): the finalize launch sizes its per-lane merge buffer for THAT plan's segment
+// count instead of the largest any of the three kernels could have produced (480p, 5 objects: 4 entries per lane instead of
+// 15 - the 256-query plan that never runs there cuts a stream into 9 segments).  Registers, not time: the launch is bound by
+// its value gather (810 MB of rows per launch at 480p, 5 objects; 82 vs 84 us, profiles/r03h_config3_kernel_stats*.csv).
+static std::mutex g_ws_mutex;
+static std::unordered_map<const void *, int> g_ws_qt;
+static void remember_select_plan(const void *workspace, int qt) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  g_ws_qt[workspace] = qt;
+}
+static int recall_select_plan(const void *workspace) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  const auto it = g_ws_qt.find(workspace);
+  return it == g_ws_qt.end() ? 0 : it->second;
+}
+
+// The kernel reads the plan from the workspace header; the host only picks how many merged candidates a lane may hold: for the
+// plan the last select launch on this workspace used, or - a workspace this process has not seen a select on - for the
+// largest of the plans a select call could have used with these sizes.
 static int launch_finalize(bool indices, void *workspace, const float *values, int64_t values_ostride, float *out,
                            int64_t out_ostride, int64_t out_pstride, int32_t *idx_out, float *w_out, int n_obj, int64_t n_mem, int n_q, int top_k,
                            hipStream_t st, const ShOut &sh = ShOut{nullptr, nullptr, 0, 0, 0, 1}) {
-  const Plan p64 = make_plan(n_obj, n_mem, n_q, top_k, QT), p128 = make_plan(n_obj, n_mem, n_q, top_k, QT2), p256 = make_plan(n_obj, n_mem, n_q, top_k, QT3);
-  int slots = p64.slots > p128.slots ? p64.slots : p128.slots;
-  slots = p256.slots > slots ? p256.slots : slots;
+  const Plan p64 = make_plan(n_obj, n_mem, n_q, top_k, QT);
+  int slots;
+  if (const int qt = recall_select_plan(workspace)) {
+    slots = make_plan(n_obj, n_mem, n_q, top_k, qt).slots;
+  } else {
+    const Plan p128 = make_plan(n_obj, n_mem, n_q, top_k, QT2), p256 = make_plan(n_obj, n_mem, n_q, top_k, QT3);
+    slots = p64.slots > p128.slots ? p64.slots : p128.slots;
+    slots = p256.slots > slots ? p256.slots : slots;
+  }
   const int per_lane = cdiv((long long)slots * p64.L, 64);       // slots bounds the segments of any stream
 #define MIVOS_FIN(N)                                                                                                              \
   (indices ? launch_finalize_n<true, N>(workspace, values, values_ostride, out, out_ostride, out_pstride, idx_out, w_out, n_obj, n_q, top_k, st, sh) \
@@ -1453,6 +1479,7 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
   if (int rc = check_select_args(keys, keys_ostride, qk, n_obj, n_mem, n_q, top_k, workspace, workspace_bytes)) return rc;
   const int qt = select_qt(f16, n_mem);
   const Plan pl = make_plan(n_obj, n_mem, n_q, top_k, qt);
+  remember_select_plan(workspace, qt);
   SelectArgs a;
   a.keys = keys; a.keys_ostride = keys_ostride; a.qk = qk; a.header = (int *)workspace;
   a.lists = (uint64_t *)((char *)workspace + HEADER_BYTES); a.n_mem = n_mem; a.n_q = n_q;
