@@ -296,3 +296,80 @@ def test_plan_cache_staleness_rules():
         net._plan = "packed"; net._stamp_plan()
         net.double()                                      # dtype move: new storages
         assert net._plan is None
+
+
+def test_counting_cut_model():
+    """csrc/memory_read.hip::count_kth, the cut of a candidate compaction, restated in Python and checked against a sort: the cut
+    keeps between k and k + slack entries and they are the largest ones, for pools of both signs, narrow bands, heavy and
+    total ties (which must fall through to the index bisection) - the invariants the kernel's exact top-k tests rely on.
+    The model mirrors the kernel step by step: score words -> 64 power-of-two buckets over [lo, max] -> suffix counts -> the
+    bucket where the count reaches k -> 6 more bits per level -> index bisection among equal score words."""
+    import numpy as np
+
+    def f2ord(f):
+        u = int(np.float32(f).view(np.uint32))
+        return (~u & 0xffffffff) if (u & 0x80000000) else (u | 0x80000000)
+
+    def count_kth(keys, k, slack, lo):
+        h = [x >> 32 for x in keys]
+        rng_ = max(h) - lo
+        shift = max(0, 26 - (32 - rng_.bit_length())) if rng_ else 0
+        width_m1, above, levels = 0xffffffff, 0, 0
+        while True:
+            levels += 1
+            hist = [0] * 64
+            for x in h:
+                d = (x - lo) & 0xffffffff
+                if x >= lo and d <= width_m1:
+                    assert (d >> shift) < 64
+                    hist[63 - (d >> shift)] += 1
+            pre = np.cumsum(hist)
+            need = k - above
+            assert need >= 1 and pre[-1] >= need                       # the range always holds the cut
+            lane = int(np.argmax(pre >= need))
+            total = above + int(pre[lane])
+            lo = lo + ((63 - lane) << shift)
+            if total <= k + slack or shift == 0:
+                break
+            above += int(pre[lane - 1]) if lane else 0
+            width_m1 = (1 << shift) - 1
+            shift = shift - 6 if shift > 6 else 0
+        prefix = lo << 32
+        if total > k + slack:                                          # equal score words straddle the cut
+            for b in range(31, -1, -1):
+                trial = prefix | (1 << b)
+                c = sum(1 for x in keys if x >= trial)
+                if c >= k:
+                    prefix, total = trial, c
+                    if c <= k + slack:
+                        break
+        return prefix, total, levels
+
+    rs = np.random.RandomState(0)
+    levels = []
+    for trial in range(600):
+        n = int(rs.randint(67, 245))
+        mode = trial % 6
+        if mode == 0:
+            s = rs.randn(n).astype(np.float32) * 3
+        elif mode == 1:
+            s = (rs.randn(n) * 5 + 20).astype(np.float32)
+        elif mode == 2:
+            s = rs.choice(np.float32([1.5, 2.5, -1.0, 0.0]), n)
+        elif mode == 3:
+            s = np.full(n, np.float32(7.25))
+        elif mode == 4:
+            s = (rs.randn(n) * 1e-3 + 40).astype(np.float32)
+        else:
+            s = np.concatenate([rs.randn(n - 30).astype(np.float32), np.float32(rs.choice([0.5, 0.75], 30))])
+        idx = rs.permutation(100000)[:n]
+        keys = [(f2ord(x) << 32) | (0xffffffff - int(i)) for x, i in zip(s, idx)]
+        k, slack = int(rs.choice([20, 50, 64])), 16
+        if n <= k + slack:
+            continue
+        lo = f2ord(np.float32(-np.inf)) if trial % 2 else min(x >> 32 for x in keys)      # first compaction / a converged threshold
+        p, c, lv = count_kth(keys, k, slack, lo)
+        levels.append(lv)
+        assert k <= c <= k + slack and c == sum(1 for x in keys if x >= p)
+        assert set(x for x in keys if x >= p) == set(sorted(keys, reverse=True)[:c])
+    assert np.median(levels) <= 2 and max(levels) <= 6
