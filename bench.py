@@ -113,6 +113,26 @@ def pmc_traffic(config, kernel_name):
     return None
 
 
+def pmc_mfma_util(config, kernel_name):
+    """Matrix-pipe busy share of the kernel instantiation `kernel_name` in bench config `config` from the committed
+    `rocprofv3 --pmc MfmaUtil` pass of that config (profiles/*config<N>*mfma_util.json, newest first; scripts/pmc_mfma_util.py):
+    sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE x SIMDs), mean over the dispatches.  None when no pass matches."""
+    import glob
+    import re
+    key = re.sub(r"[ ,]", "", kernel_name)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*config{config}*mfma_util.json")), reverse=True):
+        try:
+            table = json.load(open(path))
+        except Exception:
+            continue
+        for name, rec in table.items():
+            base = re.sub(r"^void ", "", name.replace("mivos::", "")).split("(")[0]
+            if re.sub(r"[ ,]", "", base) == key:
+                return dict(mean_pct=rec["mfma_util_mean_pct"], min_pct=rec["min_pct"], max_pct=rec["max_pct"], dispatches=rec["dispatches"],
+                            source=os.path.basename(path))
+    return None
+
+
 def event_pair_overhead(torch):
     """Seconds a HIP-event pair measures around NOTHING on a busy stream (timestamp writes + command-processor gaps):
     subtracted from every per-launch sample so that short launches (50 us) are not inflated by 10-15 %."""
@@ -163,7 +183,7 @@ def kernel_rooflines(samples, overhead=0.0, config=3, select_kernel=None):
         ach = flops / secs / 1e12
         peak = F16X3_PEAK_TFLOPS if v >= 10 else MFMA_F32_PEAK_TFLOPS
         roof = dict(bound="mfma", kernel=VARIANT_NAMES[v], achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
-                    frac=round(ach / peak, 4), traffic=pmc_traffic(config, VARIANT_NAMES[v]), launches_sampled=n,
+                    frac=round(ach / peak, 4), traffic=pmc_traffic(config, VARIANT_NAMES[v]), mfma_util_pmc=pmc_mfma_util(config, VARIANT_NAMES[v]), launches_sampled=n,
                     peak_note=("algorithmic (fp32-equivalent) FLOP/s; kernel issues 3 fp16 MFMA products per term: 2500/3"
                                if v >= 10 else "fp32 MFMA dense peak"),
                     avg_launch_us=round(secs / n * 1e6, 2), algorithmic_gflop_per_launch=round(flops / n / 1e9, 3),
@@ -181,7 +201,8 @@ def kernel_rooflines(samples, overhead=0.0, config=3, select_kernel=None):
                    peak_note=("algorithmic (fp32-equivalent) FLOP/s against 2500/3 (3 fp16 MFMA products per term); frac_of_f32_mfma_peak is the same rate "
                               "against the 157.3 TFLOP/s a single-pass fp32 MFMA kernel (the engine's exact mode, rounds 1-2) cannot exceed" if f16
                               else "fp32 MFMA dense peak"),
-                   traffic=pmc_traffic(config, select_kernel) if select_kernel else None, traffic_kernel=select_kernel, launches_sampled=n, avg_launch_us=round(secs / n * 1e6, 2),
+                   traffic=pmc_traffic(config, select_kernel) if select_kernel else None, traffic_kernel=select_kernel,
+                   mfma_util_pmc=pmc_mfma_util(config, select_kernel) if select_kernel else None, launches_sampled=n, avg_launch_us=round(secs / n * 1e6, 2),
                    algorithmic_gflop_per_launch=round(flops / n / 1e9, 3), algorithmic_bytes_per_launch=int(abytes / n),
                    hbm_gbs_algorithmic=round(abytes / secs / 1e9, 1),
                    note="FLOP = 2*K*n_mem*n_q*128 of the affinity matmul only; bytes = keys + queries read once")
