@@ -442,6 +442,42 @@ def main():
     if roof is not None:
         roof["event_pair_overhead_us"] = round(ev_overhead * 1e6, 2)
         roof["affinity"] = aff
+        # In the timed region the fusion branch of frame t runs on a side stream BESIDE the propagation kernels of frame t + 1
+        # (mivos_amd/inference_core.py: FUSE_ON_SIDE_STREAM): a HIP-event pair around a propagation launch then also measures the
+        # CUs the other stream holds.  One extra, untimed session with the branch back on the main stream gives the same kernels'
+        # rates without a neighbour: `isolated` is the kernel's own efficiency, `frac` above what it delivers in the running system.
+        roof["isolated"] = None
+        if len(cfg["interactions"]) > 1 and world == 1 and not args.no_full_session:
+            try:
+                from mivos_amd.inference_core import InferenceCore
+                side, InferenceCore.FUSE_ON_SIDE_STREAM = InferenceCore.FUSE_ON_SIDE_STREAM, False
+                try:
+                    iso = []
+                    core = InferenceCore(prop, fuse, images, K, mem_profile=0, mem_freq=args.mem_freq, device=dev)
+                    ops.PROFILE = iso
+                    for i in cfg["interactions"]:
+                        core.interact(gt[i % T], i % T)
+                    ops.PROFILE = None
+                    torch.cuda.synchronize()
+                    del core
+                finally:
+                    ops.PROFILE = None
+                    InferenceCore.FUSE_ON_SIDE_STREAM = side
+                r2, a2, _ = kernel_rooflines(iso, ev_overhead, args.config, sel)
+                agg2 = {}
+                for variant, flops, e0, e1, shape in iso:
+                    x = agg2.setdefault(variant, [0.0, 0.0, 0])
+                    x[0] += flops; x[1] += max(e0.elapsed_time(e1) * 1e-3 - ev_overhead, 1e-7); x[2] += 1
+                same = [v for v in agg2 if VARIANT_NAMES[v] == roof["kernel"]]
+                if same:
+                    f, t_, n_ = agg2[same[0]]
+                    roof["isolated"] = dict(kernel=roof["kernel"], achieved=round(f / t_ / 1e12, 2), frac=round(f / t_ / 1e12 / roof["peak"], 4),
+                                            avg_launch_us=round(t_ / n_ * 1e6, 2), launches_sampled=n_,
+                                            affinity_frac_of_f32_mfma_peak=(a2 or {}).get("frac_of_f32_mfma_peak"),
+                                            affinity_avg_launch_us=(a2 or {}).get("avg_launch_us"),
+                                            note="one untimed session, every launch sampled, fusion branch on the main stream (no concurrent kernels)")
+            except Exception as e:                      # an attribution extra must never cost the line
+                roof["isolated"] = dict(error=repr(e)[:200])
     if os.environ.get("MIVOS_BENCH_SHAPES"):          # debug: per-shape conv time inside the timed region
         agg = {}
         for variant, flops, e0, e1, shape in clock.samples:

@@ -374,6 +374,12 @@ int select_variant_pp(int M, int Cout, int nk) {
     const long long t = (long long)cdiv(M, 128) * (Cout / 256);
     const long long rounds = (t + 255) / 256;
     if (t >= 200 && (double)t / (double)(rounds * 256) >= 0.85) return 21;
+    // Long-K layers whose 128x256 tiles fill half (a quarter) of the chip: split-K by 2 (4) makes it one full round of 256
+    // workgroups with >= 18 K steps each.  The 128x128 tiles these layers used to get run at a third of the matrix-pipe
+    // utilisation of the 128x256 ones (PMC MfmaUtil 24 % vs 65 %: a wave of the 2x4 grid computes 64x32 outputs per fragment
+    // set instead of 64x64, so the LDS fragment traffic per MFMA doubles).
+    static const int wide_nk = getenv("MIVOS_PP_WIDE_NK") ? atoi(getenv("MIVOS_PP_WIDE_NK")) : 0;   // tuning: 0 = off, else the minimal K steps
+    if (wide_nk && nk >= wide_nk && (t == 128 || t == 64)) return 21;
   }
   return 20;
 }
