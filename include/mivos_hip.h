@@ -281,6 +281,11 @@ int64_t mivos_memory_read_set_q128_min(int64_t n_mem_min);
 /* ... and the depth from which it uses the 256-queries-per-workgroup kernel (8 waves, candidate regions in global scratch inside the
  * workspace; default 200000 = it takes precedence over the 128-query kernel, environment variable MIVOS_MEMREAD_Q256_MIN). */
 int64_t mivos_memory_read_set_q256_min(int64_t n_mem_min);
+/* Experimental (round 3, off by default; environment variable MIVOS_MEMREAD_HIFIRST): the 256-query kernel multiplies a key tile
+ * with the hi halves of the split operands first and completes it with the two lo products only where a bound of the dropped terms
+ * (largest key norm of the object x the query's norm x 1.25 x 2^-10) cannot rule a candidate out.  Same selection, a third of the
+ * matrix work for almost every tile.  Returns the previous setting; negative = only query. */
+int mivos_memory_read_set_hifirst(int on);
 int mivos_memory_read_select(const float *keys, int64_t keys_ostride, const float *qk, int n_obj,
                              int64_t n_mem, int n_q, int top_k, void *workspace, int64_t workspace_bytes,
                              void *stream);

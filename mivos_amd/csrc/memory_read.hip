@@ -287,6 +287,7 @@ struct SelectArgs {
   int *header;               // first 64 bytes of the workspace: the plan this launch used, for the finalize kernel
   int qt;                    // queries per workgroup (QT, QT2 for the 32-queries-per-wave kernel, QT3 for the 8-wave one)
   uint64_t *cand;            // QT3 kernel: global candidate regions, CAND3_PER_WG entries per workgroup
+  const float *kmax2;        // QT3 kernel, hi-first variant: per object, the largest squared norm of a key row (key_norm2_max_kernel)
   unsigned long long *dbg;   // profiling builds: {shader cycles, tiles} of workgroup 0 / wave 0 (NULL otherwise)
 };
 
@@ -958,6 +959,16 @@ __device__ __forceinline__ int compact_query_g(uint64_t *buf, int n0, int n1, in
   return c;
 }
 
+// HIFIRST (round 3, last experiment; off unless mivos_memory_read_set_hifirst(1)): a tile is first multiplied with the hi halves only
+// (8 MFMAs and 8 fragment reads instead of 24 and 16).  The two dropped products are bounded: x = hi + lo with |lo| <= 2^-11 |x|
+// (half an fp16 ulp; 2^-25 absolute below the normal range), so |k.q - kh.qh| <= 2^-10 (1 + 2^-10) sum |k_c| |q_c| <= 2^-10
+// (1 + 2^-10) |k| |q| (Cauchy-Schwarz).  With eps = 1.25 x 2^-10 x max_rows |k| x |q| + 1e-6 (|k| + |q|) (the margin covers the fp32
+// accumulation of 128 terms; CPU check of the bound: tests/test_host_logic.py::test_hi_first_bound_model) a wave tile in which every
+// lane's hi-only scores stay <= threshold - eps cannot hold a candidate - the exact score is <= the threshold and an equal score
+// loses its tie to the earlier positions - and is skipped; otherwise the two lo products are added to the same accumulators
+// (16 more MFMAs on fragments read then) and the tile is selected on exactly as before.  After convergence the threshold is the
+// rank-k score of 10^5 - 10^6 positions and eps ~ 1 % of the score spread: a few per cent of the wave tiles take the second pass.
+template <bool HIFIRST>
 __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectArgs a) {
   __shared__ __attribute__((aligned(16))) float ktile[NBUF3][KT * KLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -986,10 +997,12 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
     __syncthreads();                                  // previous segment completely done with LDS
 
     f32x4_t qf[16];                                   // B operand: query j, scaled like prop_net.py:86, split hi/lo (see memread_select32_kernel)
+    float my_eps = 0.f;                               // HIFIRST: bound of the two dropped products for this lane's query against any key of the object
     {
       const int q = qtile * QT3 + qslot;
       const float *qrow = a.qk + (long long)(q < a.n_q ? q : a.n_q - 1) * CK + 32 * h;
       const float d = sqrtf((float)CK);
+      float qn2 = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const float *src = qrow + 64 * (ks & 1) + 8 * (ks >> 1);
@@ -1000,9 +1013,16 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
           const float x = (e < 4 ? v0[e & 3] : v1[e & 3]) / d;
           hi[e] = (_Float16)x;
           lo[e] = (_Float16)(x - (float)hi[e]);
+          if (HIFIRST) { const float xs = (float)hi[e] + (float)lo[e]; qn2 += xs * xs; }
         }
         qf[2 * ks] = __builtin_bit_cast(f32x4_t, hi);
         qf[2 * ks + 1] = __builtin_bit_cast(f32x4_t, lo);
+      }
+      if (HIFIRST) {
+        qn2 += __shfl_xor(qn2, 32);                   // the other half of the query's channels (lane j + 32 h)
+        const float qn = sqrtf(qn2) * 1.0001f, kn = sqrtf(a.kmax2[obj]) * 1.0001f;
+        my_eps = kn * qn * (1.25f / 1024.f) + 1e-6f * (kn + qn);
+        if (!(my_eps < INFINITY)) my_eps = INFINITY;  // (NaN / inf norms: every tile takes the exact pass)
       }
 #pragma unroll
       for (int x = 0; x < 16; ++x) asm volatile("" : "+v"(qf[x]));      // finished before the key requests go out
@@ -1020,14 +1040,18 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
       for (int jj = 0; jj < 2; ++jj) *reinterpret_cast<f32x4_t *>(&ktile[buf][lrow * KLD + 4 * (lc + 16 * jj)]) = krs[jj];
     };
 
-    float my_tau = -INFINITY;
+    float my_tau = -INFINITY, my_tau_lo = -INFINITY;  // my_tau_lo = my_tau - my_eps: what a hi-only score has to exceed to matter
     int my_cnt = 0;
     auto compact_one = [&](int ql, bool force) {
       const int n0 = __builtin_amdgcn_readlane(my_cnt, ql), n1 = __builtin_amdgcn_readlane(my_cnt, ql + 32);
       if (force && n0 + n1 <= a.top_k + SLACK) return;
       float nt_tau = my_tau;
       const int c = compact_query_g(wave_regions + ql * REG3, n0, n1, a.top_k, lane, nt_tau);
-      if (j == ql) { my_cnt = (c - h + 1) >> 1; my_tau = nt_tau; }
+      if (j == ql) {
+        my_cnt = (c - h + 1) >> 1;
+        my_tau = nt_tau;
+        if (HIFIRST) my_tau_lo = (my_eps < INFINITY) ? nt_tau - my_eps : -INFINITY;
+      }
     };
     auto make_room = [&]() {
       const unsigned long long full = __ballot(my_cnt > REG3_TRIGGER);
@@ -1080,6 +1104,55 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
     // wave that has to compact a query stalls the others only if it is still behind at the end of the group.
     // Tile t: its fragments, 24 MFMAs into `cur` with the selection of tile t - 1 (`pv`) between them.
     f32x16_t accA, accB;
+    // HIFIRST: tile t is multiplied with the hi halves, tested against my_tau_lo and - rarely - completed and selected on, all in
+    // its own iteration (the other wave of the SIMD covers the wait for the accumulators; no second accumulator set).
+    auto tile_iter_hf = [&](int t, f32x4_t (&krs)[2]) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (GROUP3 - 1)) : "memory");
+      lds_store(krs, (t + GROUP3) & (NBUF3 - 1));
+      gload(krs, r0 + (t + 2 * GROUP3) * KT);
+      const float *arow = &ktile[t & (NBUF3 - 1)][j * KLD + 8 * h];
+      f32x4_t fh[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) fh[ks] = *reinterpret_cast<const f32x4_t *>(arow + 16 * ks);
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fh[ks]), __builtin_bit_cast(half8_t, qf[2 * ks]), acc, 0, 0, 0);   // hi * hi
+      asm volatile("s_nop 15" : "+v"(acc));             // (MFMA results read by the vector ALU: the hazard guard of the other kernels)
+      const int pb = r0 + t * KT;
+      if (pb + KT > r1) {                               // the stream's last tile: rows past the end of the memory never pass
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (pb + 4 * h + 8 * (r >> 2) + (r & 3) >= r1) acc[r] = -INFINITY;
+      }
+      float m16;
+      {
+        float ma, mb, mc, md;
+        asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32_e32 %0, %0, %4" : "=&v"(ma) : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+        asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32_e32 %0, %0, %4" : "=&v"(mb) : "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]));
+        asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32_e32 %0, %0, %4" : "=&v"(mc) : "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]));
+        asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32_e32 %0, %0, %4" : "=&v"(md) : "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15]));
+        asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32_e32 %0, %0, %4" : "=&v"(m16) : "v"(ma), "v"(mb), "v"(mc), "v"(md));
+      }
+      if (__builtin_expect(__ballot(m16 > my_tau_lo) != 0ull, 0)) {
+        f32x4_t fl[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) fl[ks] = *reinterpret_cast<const f32x4_t *>(arow + 16 * ks + 4);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fl[ks]), __builtin_bit_cast(half8_t, qf[2 * ks]), acc, 0, 0, 0);       // lo * hi
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fh[ks]), __builtin_bit_cast(half8_t, qf[2 * ks + 1]), acc, 0, 0, 0);   // hi * lo
+        }
+        asm volatile("s_nop 15" : "+v"(acc));
+        idx_base = (uint32_t)(pb + 4 * h);
+        make_room();
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) slice4(acc, g4);
+      }
+      if (((t + 1) & (GROUP3 - 1)) == 0) __syncthreads();
+    };
     auto tile_iter = [&](int t, f32x4_t (&krs)[2], f32x16_t &cur, const f32x16_t &pv, auto first) {
       constexpr bool SELECT = !decltype(first)::value;
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (GROUP3 - 1)) : "memory");     // tile t + GROUP3 has landed (requests complete in order)
@@ -1113,6 +1186,14 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
       if (((t + 1) & (GROUP3 - 1)) == 0) __syncthreads();
     };
     static_assert(GROUP3 == 4, "the tile loop is written out for four register sets");
+    if (HIFIRST) {
+      for (int t = 0; t < nt; t += 4) {
+        tile_iter_hf(t, kr[0]);
+        if (t + 1 < nt) tile_iter_hf(t + 1, kr[1]);
+        if (t + 2 < nt) tile_iter_hf(t + 2, kr[2]);
+        if (t + 3 < nt) tile_iter_hf(t + 3, kr[3]);
+      }
+    } else {
     tile_iter(0, kr[0], accA, accA, std::true_type{});            // (no previous tile to select on: `pv` is not read)
     if (nt > 1) tile_iter(1, kr[1], accB, accA, std::false_type{});
     if (nt > 2) tile_iter(2, kr[2], accA, accB, std::false_type{});
@@ -1122,6 +1203,7 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
       if (t + 1 < nt) tile_iter(t + 1, kr[1], accB, accA, std::false_type{});
       if (t + 2 < nt) tile_iter(t + 2, kr[2], accA, accB, std::false_type{});
       if (t + 3 < nt) tile_iter(t + 3, kr[3], accB, accA, std::false_type{});
+    }
     }
     // drain the pipeline: select on the last tile (the only one that can hold rows past the end of the memory)
     auto drain = [&](const f32x16_t &last) {
@@ -1134,8 +1216,10 @@ __global__ __launch_bounds__(512, 1) void memread_select256_kernel(const SelectA
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) slice4(masked, g4);
     };
-    if ((nt - 1) & 1) drain(accB);
-    else drain(accA);
+    if (!HIFIRST) {
+      if ((nt - 1) & 1) drain(accB);
+      else drain(accA);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the requests past the end of the segment: their registers are reused
 
     // this segment's candidate lists: for each of the wave's 32 queries between min(n, k) and k + SLACK entries
@@ -1295,6 +1379,26 @@ __global__ __launch_bounds__(256) void split_keys_kernel(const float *__restrict
   *reinterpret_cast<f32x4_t *>(q + 4) = __builtin_bit_cast(f32x4_t, lo);
 }
 
+// Largest squared norm of a (pre-split) key row per object, for the hi-first select kernel's bound: thread (row, chunk) sums
+// (hi + lo)^2 over its 8 channels, the 16 chunks of a row are added up across lanes, the block's maximum goes out through
+// one atomic per wave (non-negative floats order like their bit patterns).  `out` must be zero before the launch.
+__global__ __launch_bounds__(256) void key_norm2_max_kernel(const float *__restrict__ split, long long ostride, long long n_rows,
+                                                            float *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long row = i >> 4;
+  float s2 = 0.f;
+  if (row < n_rows) {
+    const float *p = split + (long long)blockIdx.y * ostride + row * CK + 8 * (i & 15);
+    const half8_t hi = __builtin_bit_cast(half8_t, *reinterpret_cast<const f32x4_t *>(p));
+    const half8_t lo = __builtin_bit_cast(half8_t, *reinterpret_cast<const f32x4_t *>(p + 4));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float x = (float)hi[e] + (float)lo[e]; s2 += x * x; }
+  }
+  s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 8);      // the row's 16 chunks
+  s2 = fmaxf(s2, __shfl_xor(s2, 16)); s2 = fmaxf(s2, __shfl_xor(s2, 32));                                    // the wave's 4 rows
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(out) + blockIdx.y, __float_as_uint(s2));
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------
 struct Plan {
   int qt, n_qtiles, streams, tps, n_wg, tiles_per_wg, slots, L;
@@ -1375,6 +1479,16 @@ static long long max_lists_bytes(int n_obj, long long n_mem, int n_q, int top_k)
   return (m + 255) / 256 * 256;
 }
 static long long cand3_bytes() { return (long long)compute_units() * CAND3_PER_WG * 8; }
+static long long kmax_bytes(int n_obj) { return ((long long)n_obj * 4 + 255) / 256 * 256; }   // hi-first kernel: max squared key norm per object
+static std::atomic<int> g_hifirst{-1};
+static int hifirst() {
+  int v = g_hifirst.load(std::memory_order_relaxed);
+  if (v < 0) {
+    v = getenv("MIVOS_MEMREAD_HIFIRST") ? atoi(getenv("MIVOS_MEMREAD_HIFIRST")) : 0;
+    g_hifirst.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 
 static int check_select_args(const float *keys, int64_t keys_ostride, const float *qk, int n_obj, int64_t n_mem, int n_q,
                              int top_k, void *workspace, int64_t workspace_bytes) {
@@ -1451,7 +1565,13 @@ using namespace mivos;
 
 extern "C" int64_t mivos_memory_read_workspace_bytes(int n_obj, int64_t n_mem, int n_q, int top_k) {
   if (n_obj < 1 || n_q < 1 || n_mem < 1 || top_k < 1) return 0;
-  return HEADER_BYTES + max_lists_bytes(n_obj, n_mem, n_q, top_k) + cand3_bytes();
+  return HEADER_BYTES + max_lists_bytes(n_obj, n_mem, n_q, top_k) + cand3_bytes() + kmax_bytes(n_obj);
+}
+
+extern "C" int mivos_memory_read_set_hifirst(int on) {
+  const int old = hifirst();
+  if (on >= 0) g_hifirst.store(on ? 1 : 0, std::memory_order_relaxed);
+  return old;
 }
 
 extern "C" int64_t mivos_memory_read_set_q256_min(int64_t n_mem_min) {
@@ -1486,6 +1606,7 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
   a.top_k = top_k; a.n_qtiles = pl.n_qtiles; a.tps = pl.tps; a.total_tiles = pl.total; a.tiles_per_wg = pl.tiles_per_wg;
   a.slots = pl.slots; a.L = pl.L; a.qt = qt;
   a.cand = (uint64_t *)((char *)workspace + HEADER_BYTES + max_lists_bytes(n_obj, n_mem, n_q, top_k));
+  a.kmax2 = nullptr;
   static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;          // profiling only
   static const int dbg = getenv("MIVOS_MEMREAD_DBG") ? atoi(getenv("MIVOS_MEMREAD_DBG")) : 0;   // profiling only: prints cycles per tile
   static unsigned long long *dbg_buf = nullptr;
@@ -1503,7 +1624,16 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
 #define MIVOS_SEL32(ABL, BR) hipLaunchKernelGGL((memread_select32_kernel<ABL, BR>), grid, block, 0, st, a)
   if (qt == QT3) {
     if ((long long)pl.n_wg * CAND3_PER_WG * 8 > cand3_bytes()) return fail(MIVOS_ERR_INVALID_ARGUMENT, "memory_read: more workgroups than candidate scratch");
-    hipLaunchKernelGGL(memread_select256_kernel, grid, dim3(512), 0, st, a);
+    if (hifirst()) {
+      float *kmax2 = (float *)((char *)a.cand + cand3_bytes());
+      if (hipMemsetAsync(kmax2, 0, (size_t)n_obj * 4, st) != hipSuccess) return fail(MIVOS_ERR_LAUNCH, "memory_read: hipMemsetAsync");
+      const long long blocks = (n_mem * 16 + 255) / 256;
+      hipLaunchKernelGGL(key_norm2_max_kernel, dim3((unsigned)blocks, n_obj), dim3(256), 0, st, keys, (long long)keys_ostride, (long long)n_mem, kmax2);
+      a.kmax2 = kmax2;
+      hipLaunchKernelGGL(memread_select256_kernel<true>, grid, dim3(512), 0, st, a);
+    } else {
+      hipLaunchKernelGGL(memread_select256_kernel<false>, grid, dim3(512), 0, st, a);
+    }
   } else if (qt == QT2) {
     if (abl == 1) MIVOS_SEL32(1, false);
     else if (br) MIVOS_SEL32(0, true);

@@ -52,19 +52,22 @@ def precision(request):
     ops.CONV_PRECISION = old
 
 
-@pytest.fixture(params=["f32", "f16x3", "f16x3-q128", "f16x3-q256"])
+@pytest.fixture(params=["f32", "f16x3", "f16x3-q128", "f16x3-q256", "f16x3-q256hf"])
 def mem_precision(request):
-    """The four affinity kernels of the memory read: exact fp32 MFMA, error-compensated fp16 MFMA with 16 queries per wave,
-    with 32 queries per wave (128 per workgroup, the long-memory kernel) and with 8 waves of 32 (256 per workgroup, candidate
-    regions in global scratch) - the long-memory kernels forced onto the small test shapes."""
+    """The affinity kernels of the memory read: exact fp32 MFMA, error-compensated fp16 MFMA with 16 queries per wave,
+    with 32 queries per wave (128 per workgroup, the long-memory kernel), with 8 waves of 32 (256 per workgroup, candidate
+    regions in global scratch) and the latter's hi-first variant (hi x hi product first, lo products only where a bound of
+    them cannot rule candidates out) - the long-memory kernels forced onto the small test shapes."""
     from mivos_amd import _lib
     old, ops.CONV_PRECISION = ops.CONV_PRECISION, request.param.split("-")[0]
     old_min = _lib.load().mivos_memory_read_set_q128_min(0 if request.param.endswith("q128") else 1 << 40)
-    old_256 = _lib.load().mivos_memory_read_set_q256_min(0 if request.param.endswith("q256") else 1 << 60)
+    old_256 = _lib.load().mivos_memory_read_set_q256_min(0 if "q256" in request.param else 1 << 60)
+    old_hf = _lib.load().mivos_memory_read_set_hifirst(1 if request.param.endswith("hf") else 0)
     yield request.param
     ops.CONV_PRECISION = old
     _lib.load().mivos_memory_read_set_q128_min(old_min)
     _lib.load().mivos_memory_read_set_q256_min(old_256)
+    _lib.load().mivos_memory_read_set_hifirst(old_hf)
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c[:8])))
@@ -539,6 +542,12 @@ def test_memory_read_deep_bank_1080p_vs_chunked_oracle(frames, scale):
             assert _lib.load().mivos_memory_read_plan(K, frames * hw, hw, top_k, 1, plan) == 0 and plan[6] == 256
             got256 = ops.memory_read(keys, vals, q, top_k, keys_split=ks)
             idx256, _ = ops.memory_read_indices(keys, q, top_k, keys_split=ks)
+            oldhf = _lib.load().mivos_memory_read_set_hifirst(1)                    # ... and its hi-first variant
+            try:
+                got_hf = ops.memory_read(keys, vals, q, top_k, keys_split=ks)
+                idx_hf, _ = ops.memory_read_indices(keys, q, top_k, keys_split=ks)
+            finally:
+                _lib.load().mivos_memory_read_set_hifirst(oldhf)
         finally:
             _lib.load().mivos_memory_read_set_q256_min(old256)
         ops.CONV_PRECISION = "f32"
@@ -550,7 +559,7 @@ def test_memory_read_deep_bank_1080p_vs_chunked_oracle(frames, scale):
     r32 = CR.memory_read_rows(keys, vals, q, top_k, dtype=torch.float32)
     clear = r64["margin"] > 1e-5                                                  # [K, n_q]
     ref_sets = torch.sort(r64["idx"], dim=2)[0]
-    for name, o_got, o_idx in (("f16x3/select32", got, idx), ("f16x3/select256", got256, idx256), ("f32", got32, idx32)):
+    for name, o_got, o_idx in (("f16x3/default", got, idx), ("f16x3/select256", got256, idx256), ("f16x3/select256 hi-first", got_hf, idx_hf), ("f32", got32, idx32)):
         d64 = (o_got.double() - r64["readout"]).abs().amax(2)
         d32 = (o_got - r32["readout"]).abs().amax(2)
         same = (torch.sort(o_idx.long(), dim=2)[0] == ref_sets).all(dim=2)

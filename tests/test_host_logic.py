@@ -411,3 +411,31 @@ def test_bench_roofline_helpers_on_committed_profiles():
     assert abs(aff["achieved"] - 87.5) < 1e-6 and abs(aff["frac_of_f32_mfma_peak"] - 87.5 / 157.3) < 1e-3 and aff["finalize"]["avg_launch_us"] == 80.0
     assert set(table) == {"conv_f16x3_pp_kernel<128,128,2,4,0>", "conv_f16x3_pp_kernel<128,256,2,4,0>", "memread_select_kernel", "memread_finalize_kernel"}
     assert bench.kernel_rooflines([], 0.0, 3, None) == (None, None, {})
+
+
+def test_hi_first_bound_model():
+    """The bound the hi-first select kernel (csrc/memory_read.hip, memread_select256_kernel<true>) skips key tiles by: with
+    x = hi + lo the fp16 split of the engine, |sum (kh ql + kl qh)| <= 1.25 x 2^-10 |k| |q| + 1e-6 (|k| + |q|), over magnitudes
+    from 1e-6 (fp16 subnormals) to 1e2 and sign-aligned vectors (the worst case of the Cauchy-Schwarz step)."""
+    import numpy as np
+
+    def split(x):
+        hi = x.astype(np.float16)
+        lo = (x - hi.astype(np.float32)).astype(np.float16)
+        return hi.astype(np.float64), lo.astype(np.float64)
+
+    rs = np.random.RandomState(1)
+    worst = 0.0
+    for trial in range(4000):
+        k = (rs.randn(128) * [1, 3, 1e-3, 100, 1e-6][trial % 5]).astype(np.float32)
+        q = (rs.randn(128) * [1, 3, 10, 1e-2, 1e3][(trial // 5) % 5]).astype(np.float32)
+        if trial % 7 == 0:
+            k, q = np.abs(k), np.abs(q)
+        kh, kl = split(k)
+        qh, ql = split(q)
+        dropped = abs(np.sum(kl * qh) + np.sum(kh * ql))
+        kn, qn = np.sqrt(np.sum((kh + kl) ** 2)), np.sqrt(np.sum((qh + ql) ** 2))
+        eps = kn * qn * (1.25 / 1024) + 1e-6 * (kn + qn)
+        assert dropped <= eps
+        worst = max(worst, dropped / eps)
+    assert worst < 0.5                                   # (and the fp32 accumulation of 128 terms, <= 1e-5 |k| |q|, fits in the margin)
