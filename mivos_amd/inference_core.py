@@ -259,10 +259,11 @@ class InferenceCore:
         return closest
 
     @_on_core_device
-    def fuse_one_frame(self, tc, tr, ti, prev_mask, curr_mask, mk16, qk16):
-        """Difference-aware fusion of the previous result with the new propagation for frame ti
-        (reference inference_core.py:202-217), all K objects in one batch.  mk16: [K, h*w, 128] rows or
-        the reference's [K,128,1,h,w]; qk16: NHWC [1,h,w,128] or the reference's [1,128,h,w]."""
+    def fuse_logits(self, tc, tr, ti, prev_mask, curr_mask, mk16, qk16):
+        """FusionNet's logits [K,nh,nw,1] for frame ti (reference inference_core.py:202-215 up to the sigmoid), all K objects in
+        one batch: aligned difference maps (get_attention) + FusionNet on (frame, previous result, new propagation, maps,
+        normalised distances).  mk16: [K, h*w, 128] rows or the reference's [K,128,1,h,w]; qk16: NHWC [1,h,w,128] or the
+        reference's [1,128,h,w]."""
         assert tc < ti < tr or tr < ti < tc
         K, P = self.k, self.nh * self.nw
         nc, nr = abs(tc - ti) / abs(tc - tr), abs(tr - ti) / abs(tc - tr)
@@ -276,9 +277,23 @@ class InferenceCore:
         curr = curr_mask.to(self.device)
         im = self.get_image_buffered(ti).contiguous()
         prev_k, curr_k = prev[1:], curr[1:]
-        w = ops.sigmoid(self.fuse_net.run_planes((im, 0), (prev_k, prev_k.stride(0)), (curr_k, curr_k.stride(0)),
-                                                 (attn, 2 * P), (nc, nr), K))               # [K,nh,nw,1]
-        return ops.aggregate(w.view(K, 1, self.nh, self.nw), keep_bg=True)
+        return self.fuse_net.run_planes((im, 0), (prev_k, prev_k.stride(0)), (curr_k, curr_k.stride(0)),
+                                        (attn, 2 * P), (nc, nr), K)                         # [K,nh,nw,1]
+
+    @_on_core_device
+    def fuse_one_frame(self, tc, tr, ti, prev_mask, curr_mask, mk16, qk16):
+        """Difference-aware fusion of the previous result with the new propagation for frame ti
+        (reference inference_core.py:202-217): sigmoid of fuse_logits, aggregated with the soft background."""
+        w = ops.sigmoid(self.fuse_logits(tc, tr, ti, prev_mask, curr_mask, mk16, qk16))
+        return ops.aggregate(w.view(self.k, 1, self.nh, self.nw), keep_bg=True)
+
+    def _prepare_diff(self, mask, old):
+        """Positive / negative difference of the new (padded, one-hot) mask of the interacted frame against its previous
+        probabilities (reference :236-238), full resolution and area-pooled to the key grid (the same for every fused frame)."""
+        K = self.k
+        self.pos_mask_diff, self.neg_mask_diff = ops.mask_diff(mask, old)
+        self._pos16 = ops.area_pool16(self.pos_mask_diff[1:].reshape(K, self.nh, self.nw)).view(K, -1)
+        self._neg16 = ops.area_pool16(self.neg_mask_diff[1:].reshape(K, self.nh, self.nw)).view(K, -1)
 
     # ---- public entry points ------------------------------------------------------------------
     @_on_core_device
@@ -289,12 +304,8 @@ class InferenceCore:
         mask = mask.to(self.device).float()
         mask, _ = pad_divide_by(mask, 16, mask.shape[-2:])
         mask = mask.contiguous()
-        old = self.prob[:, idx].to(self.device)
-        self.pos_mask_diff, self.neg_mask_diff = ops.mask_diff(mask, old)
-        # 1/16-resolution difference maps are the same for every fused frame of this interaction
         K = self.k
-        self._pos16 = ops.area_pool16(self.pos_mask_diff[1:].reshape(K, self.nh, self.nw)).view(K, -1)
-        self._neg16 = ops.area_pool16(self.neg_mask_diff[1:].reshape(K, self.nh, self.nw)).view(K, -1)
+        self._prepare_diff(mask, self.prob[:, idx].to(self.device))
         self.prob[:, idx] = mask.to(self.result_dev)
 
         key_k, key_v = self.prop_net.memorize_into(self.get_image_buffered(idx), mask[1:])   # [K,h,w,C]

@@ -325,6 +325,10 @@ class OracleCore:
         self.query_buf, self.interacted = {}, set()
         self.certain_k = self.certain_v = None
         self.trace, self.logits, self.propagated = [], {}, 0
+        # step_hook(record): called once per propagated frame with everything that went into and came out of the step (bank
+        # views, query features, decoder logits, aggregated output, the frame's memorised key / value, the fusion branch's
+        # inputs and logits) - the tests run the engine on the SAME inputs ("teacher forced") and compare each stage
+        self.step_hook = None
 
     def _query(self, ti):                                                      # :110-120
         if ti not in self.query_buf:
@@ -367,16 +371,29 @@ class OracleCore:
                 TOPK_GAP = None
             self.logits[ti] = logit
             out = aggregate_wbg(torch.sigmoid(logit), keep_bg=True)
+            rec = None
+            if self.step_hook is not None:
+                rec = dict(ti=ti, idx=idx, closest=closest, n_mem=m, keys=keys[:, :, :m].clone(), values=values[:, :, :m].clone(), query=q,
+                           logit=logit, out=out, memorized=None, fuse=None)
             if ti != end:
-                keys[:, :, m_front:m_front + 1], values[:, :, m_front:m_front + 1] = self._memorize(ti, out[1:])
+                mem_kv = self._memorize(ti, out[1:])
+                keys[:, :, m_front:m_front + 1], values[:, :, m_front:m_front + 1] = mem_kv
+                if rec is not None:
+                    rec["memorized"] = mem_kv
                 if abs(ti - last_ti) >= self.mem_freq:
                     m_front, last_ti, prev_in_mem = m_front + 1, ti, True
                 else:
                     prev_in_mem = False
             if fuse:
-                self.prob[:, ti] = self.fuse_one_frame(closest, idx, ti, self.prob[:, ti], out, key_k, q[3])
+                prev = self.prob[:, ti].clone()
+                self.prob[:, ti] = self.fuse_one_frame(closest, idx, ti, prev, out, key_k, q[3])
+                if rec is not None:
+                    rec["fuse"] = dict(prev=prev, curr=out, key_k=key_k, qk16=q[3], logits=self.last_fuse_logits, attn=self.last_fuse_attn,
+                                       fused=self.prob[:, ti].clone())
             else:
                 self.prob[:, ti] = out
+            if rec is not None:
+                self.step_hook(rec)
             self.propagated += 1
         return closest
 
@@ -385,10 +402,15 @@ class OracleCore:
         nc, nr = abs(tc - ti) / abs(tc - tr), abs(tr - ti) / abs(tc - tr)
         dist = torch.tensor([[nc, nr]], dtype=torch.float32).to(self.dtype)
         prob = torch.zeros((self.k, 1, self.nh, self.nw), dtype=self.dtype)
+        logits, attns = [], []
         for k in range(1, self.k + 1):
             attn = get_attention(mk16[k - 1:k], self.pos_diff[k:k + 1], self.neg_diff[k:k + 1], qk16)
             self.trace.append(f"F({nc:.2f},{nr:.2f})")
-            prob[k - 1] = torch.sigmoid(fusion_net(self.fsd, self.images[:, ti], prev[k:k + 1], curr[k:k + 1], attn, dist))
+            z = fusion_net(self.fsd, self.images[:, ti], prev[k:k + 1], curr[k:k + 1], attn, dist)
+            logits.append(z)
+            attns.append(attn)
+            prob[k - 1] = torch.sigmoid(z)
+        self.last_fuse_logits, self.last_fuse_attn = torch.cat(logits, 0), torch.cat(attns, 0)      # [K,1,nh,nw], [K,2,nh,nw]
         return aggregate_wbg(prob, keep_bg=True)
 
     def interact(self, mask, idx):                                             # :219-271
@@ -411,6 +433,16 @@ class OracleCore:
         out = self.masks[:, 0, lh:self.nh - uh, lw:self.nw - uw]
         self.np_masks = out.numpy().astype(np.uint8)
         return self.np_masks
+
+    def update_mask_only(self, prob_mask, idx):                                # :273-293
+        """Interaction without propagation: argmax over the K+1 channels of the (padded) prob_mask -> masks[idx], cropped ->
+        np_masks[idx]; every other frame keeps its result."""
+        mask = torch.argmax(prob_mask, 0)
+        self.masks[idx] = mask
+        lw, uw, lh, uh = self.pad
+        self.np_masks[idx] = mask[0, lh:self.nh - uh, lw:self.nw - uw].numpy().astype(np.uint8)
+        return self.np_masks
+
 
 class OracleGenerator:
     """Restatement of FusionGenerator (generation/fusion_generator.py:12-101): propagation from one annotated frame to both range

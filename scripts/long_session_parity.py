@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""Long closed-loop parity run: BASELINE config 3's FULL session (480x854, 70 frames, 5 objects, top_k = 50, mem_freq = 5,
+interact(0) = 69 propagated frames, then interact(69) = 68 propagated + fused frames) on the engine against the CPU oracle in
+fp32 (== the unmodified reference bit for bit, tests/test_oracle_golden.py) and, optionally, in fp64 (arbitration).  Per frame
+and interaction: mask IoU, mismatching pixels, max / quantiles of |dprob|.  Too long for `pytest -m gpu` (137 CPU frames of ~3 s
+in fp32, ~3x that in fp64); run once per round under gpurun and commit the JSON under profiles/.
+
+    python scripts/long_session_parity.py oracle --dtype fp32 --out /tmp/long32     # CPU only (can run beside GPU work)
+    python scripts/long_session_parity.py oracle --dtype fp64 --out /tmp/long64
+    python scripts/long_session_parity.py engine --ref32 /tmp/long32 [--ref64 /tmp/long64] --json gpurun_out/long_session_parity.json
+
+The oracle phase writes prob_<n>.npy / masks_<n>.npy after every interaction and a `done` marker."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CFG = dict(frames=70, height=480, width=854, objects=5, top_k=50, mem_freq=5, seed=100, interactions=[0, 69])
+
+
+def clip(cfg):
+    from mivos_amd.util import synthetic
+    return synthetic.synthetic_clip(cfg["frames"], cfg["height"], cfg["width"], cfg["objects"], seed=cfg["seed"])
+
+
+def run_oracle(args, cfg):
+    from oracle import stm_oracle as O
+    from mivos_amd.util import synthetic
+    torch.set_num_threads(args.threads)
+    os.makedirs(args.out, exist_ok=True)
+    dt = torch.float64 if args.dtype == "fp64" else torch.float32
+    images, gt = clip(cfg)
+    core = O.OracleCore(synthetic.make_prop_state(0), synthetic.make_fuse_state(0), images, cfg["objects"], mem_freq=cfg["mem_freq"],
+                        top_k=cfg["top_k"], dtype=dt, record_margins=True)
+    t0 = time.perf_counter()
+    for n, idx in enumerate(cfg["interactions"]):
+        masks = core.interact(gt[idx], idx)
+        np.save(os.path.join(args.out, f"masks_{n}.npy"), masks)
+        np.save(os.path.join(args.out, f"prob_{n}.npy"), core.prob.numpy())
+        with open(os.path.join(args.out, f"margins_{n}.json"), "w") as f:
+            json.dump({str(k): v for k, v in core.topk_margin.items()}, f)
+        print(f"oracle {args.dtype}: interact({idx}) done, {core.propagated} frames, {time.perf_counter() - t0:.0f} s", flush=True)
+    with open(os.path.join(args.out, "done"), "w") as f:
+        json.dump(dict(seconds=time.perf_counter() - t0, frames=core.propagated, threads=args.threads, dtype=args.dtype), f)
+
+
+def quantiles(x, qs=(0.999, 0.9999)):
+    flat = x.flatten()
+    return [float(flat.kthvalue(max(1, int(round(flat.numel() * q)))).values) for q in qs]
+
+
+def run_engine(args, cfg):
+    from mivos_amd.inference_core import InferenceCore
+    from mivos_amd.model.fusion_net import FusionNet
+    from mivos_amd.model.propagation.prop_net import PropagationNetwork
+    from mivos_amd.util import synthetic
+    from mivos_amd.util.tensor_util import compute_np_iou
+    torch.set_grad_enabled(False)
+    dev = "cuda:0"
+    t_wait = time.time()
+    for d in (args.ref32, args.ref64):
+        while d and not os.path.exists(os.path.join(d, "done")):
+            if time.time() - t_wait > args.wait:
+                if d == args.ref64:
+                    print(f"fp64 oracle not finished after {args.wait} s: continuing without arbitration", flush=True)
+                    args.ref64 = None
+                    break
+                raise SystemExit(f"oracle results missing in {d}")
+            time.sleep(5)
+    K = cfg["objects"]
+    prop, fuse = PropagationNetwork(top_k=cfg["top_k"]), FusionNet()
+    prop.load_state_dict(synthetic.make_prop_state(0))
+    fuse.load_state_dict(synthetic.make_fuse_state(0))
+    prop, fuse = prop.to(dev).eval(), fuse.to(dev).eval()
+    images, gt = clip(cfg)
+    core = InferenceCore(prop, fuse, images, K, mem_freq=cfg["mem_freq"], device=dev)
+    out = dict(config=cfg, oracle_fp32=json.load(open(os.path.join(args.ref32, "done"))),
+               oracle_fp64=json.load(open(os.path.join(args.ref64, "done"))) if args.ref64 else None, interactions=[])
+    for n, idx in enumerate(cfg["interactions"]):
+        t0 = time.perf_counter()
+        masks = core.interact(gt[idx], idx)
+        torch.cuda.synchronize()
+        secs = time.perf_counter() - t0
+        ref_m = np.load(os.path.join(args.ref32, f"masks_{n}.npy"))
+        ref_p = torch.from_numpy(np.load(os.path.join(args.ref32, f"prob_{n}.npy")))
+        eng_p = core.prob.cpu()
+        p64 = torch.from_numpy(np.load(os.path.join(args.ref64, f"prob_{n}.npy"))) if args.ref64 else None
+        m64 = np.load(os.path.join(args.ref64, f"masks_{n}.npy")) if args.ref64 else None
+        margins = json.load(open(os.path.join(args.ref32, f"margins_{n}.json")))
+        frames = []
+        for t in range(cfg["frames"]):
+            iou = float(np.mean([compute_np_iou(masks[t] == j, ref_m[t] == j) for j in range(1, K + 1)]))
+            d = (eng_p[:, t] - ref_p[:, t]).abs()
+            q = quantiles(d)
+            rec = dict(frame=t, iou=round(iou, 6), mismatch_px=int((masks[t] != ref_m[t]).sum()), dprob_max=float(d.max()), dprob_q999=q[0], dprob_q9999=q[1],
+                       frac_gt_1e3=float((d > 1e-3).float().mean()), topk_margin_fp32=margins.get(str(t)))
+            if p64 is not None:
+                e = (eng_p[:, t].double() - p64[:, t]).abs()
+                r = (ref_p[:, t].double() - p64[:, t]).abs()
+                rec.update(engine_vs_fp64_max=float(e.max()), ref32_vs_fp64_max=float(r.max()), engine_vs_fp64_q999=quantiles(e)[0], ref32_vs_fp64_q999=quantiles(r)[0],
+                           iou_engine_vs_fp64=round(float(np.mean([compute_np_iou(masks[t] == j, m64[t] == j) for j in range(1, K + 1)])), 6),
+                           iou_ref32_vs_fp64=round(float(np.mean([compute_np_iou(ref_m[t] == j, m64[t] == j) for j in range(1, K + 1)])), 6))
+            frames.append(rec)
+        live = [f for f in frames if f["frame"] not in cfg["interactions"][:n + 1]]
+        far = frames[cfg["frames"] - 1] if idx == 0 else frames[1]
+        summ = dict(interact=idx, engine_seconds=round(secs, 3), min_iou=min(f["iou"] for f in live), mean_iou=round(float(np.mean([f["iou"] for f in live])), 6),
+                    iou_at_farthest_frame=far["iou"], farthest_frame=far["frame"], frames_below_0999=[f["frame"] for f in live if f["iou"] < 0.999],
+                    total_mismatch_px=sum(f["mismatch_px"] for f in live), pixels_per_frame=cfg["height"] * cfg["width"],
+                    max_dprob=max(f["dprob_max"] for f in live), worst_q999=max(f["dprob_q999"] for f in live), worst_q9999=max(f["dprob_q9999"] for f in live))
+        if p64 is not None:
+            summ.update(min_iou_engine_vs_fp64=min(f["iou_engine_vs_fp64"] for f in live), min_iou_ref32_vs_fp64=min(f["iou_ref32_vs_fp64"] for f in live),
+                        max_engine_vs_fp64=max(f["engine_vs_fp64_max"] for f in live), max_ref32_vs_fp64=max(f["ref32_vs_fp64_max"] for f in live),
+                        worst_q999_engine_vs_fp64=max(f["engine_vs_fp64_q999"] for f in live), worst_q999_ref32_vs_fp64=max(f["ref32_vs_fp64_q999"] for f in live))
+        print(json.dumps(summ), flush=True)
+        out["interactions"].append(dict(summary=summ, frames=frames))
+    os.makedirs(os.path.dirname(os.path.abspath(args.json)), exist_ok=True)
+    with open(args.json, "w") as f:
+        json.dump(out, f)
+    print("wrote", args.json)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("phase", choices=("oracle", "engine"))
+    ap.add_argument("--dtype", default="fp32", choices=("fp32", "fp64"))
+    ap.add_argument("--out", default="/tmp/long32")
+    ap.add_argument("--threads", type=int, default=32)
+    ap.add_argument("--ref32", default="/tmp/long32")
+    ap.add_argument("--ref64", default=None)
+    ap.add_argument("--wait", type=int, default=1800, help="engine phase: seconds to wait for the oracle results")
+    ap.add_argument("--json", default=os.path.join(ROOT, "gpurun_out", "long_session_parity.json"))
+    ap.add_argument("--frames", type=int, default=None, help="shorter clip (smoke runs)")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--objects", type=int, default=None)
+    args = ap.parse_args()
+    cfg = dict(CFG)
+    for k in ("frames", "height", "width", "objects"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    cfg["interactions"] = [0, cfg["frames"] - 1]
+    torch.set_grad_enabled(False)
+    (run_oracle if args.phase == "oracle" else run_engine)(args, cfg)
+
+
+if __name__ == "__main__":
+    main()

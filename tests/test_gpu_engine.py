@@ -45,10 +45,14 @@ def mean_iou(a, b, k):
 
 
 ARBITRATION_FACTOR, ARBITRATION_FLOOR = 2.0, 2.5e-4
-TIE_MARGIN, TIE_QUANTILE, TIE_CAP = 1e-3, 5e-3, 5e-2
+TIE_MARGIN, TIE_QUANTILE, TIE_CAP = 1e-3, 1e-4, 5e-2
+# FROZEN (round 4): the tie clause's quantile is the documented 1e-4.  A test that needs more passes its own
+# `tie_quantile` with the justification written at the call site; every record names the clause each frame passed through and
+# the quantile in force, and the record of the full suite is committed per round (profiles/r04*_parity_ratios.jsonl,
+# scripts/parity_clauses.py lists the frames that did not pass the strict clause).
 
 
-def fp64_gate(tag, eng_prob, ref32_prob, ref64_prob, margins=None):
+def fp64_gate(tag, eng_prob, ref32_prob, ref64_prob, margins=None, tie_quantile=TIE_QUANTILE):
     """The closed-loop parity gate, fp64-arbitrated.  Per frame f, with e = |engine - fp64| and r = |reference_fp32 -
     fp64| (the reference's OWN fp32 arithmetic against an fp64 run of the same algorithm):
 
@@ -62,9 +66,10 @@ def fp64_gate(tag, eng_prob, ref32_prob, ref64_prob, margins=None):
     those sessions - and only for them: `margins` holds, per propagated frame, the smallest rank-k / k+1 gap of the fp64 run; a frame
     qualifies when that gap is below TIE_MARGIN = 1e-3 somewhere in the session so far (flips travel through the memory bank) -
 
-      tie clause      all but TIE_QUANTILE = 5e-3 of the frame's pixels obey the strict bound (quantile against quantile: one
-                      flipped neighbour at the 1/16-resolution grid reaches ~32 x 32 output pixels through the decoder, 0.25 % of a
-                      480p frame), and max e_f <= TIE_CAP = 5e-2 (what a flipped neighbour of weight ~1/k can move)
+      tie clause      all but `tie_quantile` (default TIE_QUANTILE = 1e-4) of the frame's pixels obey the strict bound (quantile
+                      against quantile) and max e_f <= TIE_CAP = 5e-2 (what a flipped neighbour of weight ~1/k can move).  One
+                      flipped neighbour at the 1/16-resolution grid reaches ~32 x 32 output pixels through the decoder = 0.25 % of
+                      a 480p frame: a test whose session holds such a flip passes tie_quantile=5e-3 and says so at its call site.
 
     Prints the numbers, appends them to gpurun_out/parity_ratios.jsonl (a record per run) and returns (passed, record)."""
     e = (eng_prob.cpu().double() - ref64_prob).abs()
@@ -87,10 +92,10 @@ def fp64_gate(tag, eng_prob, ref32_prob, ref64_prob, margins=None):
             clause.append("strict"); eq.append(None); rq.append(None)
             continue
         et, rt = e[:, t].reshape(-1), r[:, t].reshape(-1)
-        kth = max(1, int(round(et.numel() * (1.0 - TIE_QUANTILE))))
+        kth = max(1, int(round(et.numel() * (1.0 - tie_quantile))))
         e_q, r_q = float(et.kthvalue(kth).values), float(rt.kthvalue(kth).values)
-        eq.append([e_q] + [float(et.kthvalue(max(1, int(round(et.numel() * (1.0 - qq))))).values) for qq in (1e-3, 1e-4)])   # at 5e-3, 1e-3, 1e-4
-        rq.append([r_q] + [float(rt.kthvalue(max(1, int(round(rt.numel() * (1.0 - qq))))).values) for qq in (1e-3, 1e-4)])
+        eq.append([e_q] + [float(et.kthvalue(max(1, int(round(et.numel() * (1.0 - qq))))).values) for qq in (5e-3, 1e-3, 1e-4)])   # at tie_quantile, 5e-3, 1e-3, 1e-4
+        rq.append([r_q] + [float(rt.kthvalue(max(1, int(round(rt.numel() * (1.0 - qq))))).values) for qq in (5e-3, 1e-3, 1e-4)])
         near_tie = margins is not None and min(seen.values(), default=float("inf")) < TIE_MARGIN
         if near_tie and e_q <= ARBITRATION_FACTOR * r_q + ARBITRATION_FLOOR and float(ef[t]) <= TIE_CAP:
             clause.append("tie")
@@ -98,7 +103,7 @@ def fp64_gate(tag, eng_prob, ref32_prob, ref64_prob, margins=None):
             clause.append("FAIL"); ok = False
     margin = float((ARBITRATION_FACTOR * rf + ARBITRATION_FLOOR - ef).min())
     rec = dict(test=tag, frames=int(T), engine_vs_fp64_max=float(ef.max()), ref32_vs_fp64_max=float(rf.max()),
-               worst_frame_ratio=round(ratio, 3), gate_margin=margin, clauses=clause,
+               worst_frame_ratio=round(ratio, 3), gate_margin=margin, clauses=clause, tie_quantile=tie_quantile, passed=ok,
                min_topk_margin_fp64=(min(margins.values()) if margins else None),
                frac_gt_1e3_engine=float((e > 1e-3).double().mean()), frac_gt_1e3_ref32=float((r > 1e-3).double().mean()),
                per_frame_engine=[float(x) for x in ef], per_frame_ref32=[float(x) for x in rf],
@@ -327,9 +332,39 @@ def test_end_to_end_golden(nets, golden_dir, synthetic_states):
         ok, rec = fp64_gate(f"e2e_golden[{n}]", core.prob, T(g[f"prob_{n}"]), o64.prob, o64.topk_margin)
         assert ok, rec
     assert core.propagated_frames == 6 + 5 + 4
-    # update_mask_only keeps its contract
-    m = core.update_mask_only(core.prob[:, 2], 2)
-    assert m.shape == (c["t"], c["h"], c["w"])
+
+
+def test_update_mask_only_golden(nets, golden_dir):
+    """InferenceCore.update_mask_only (reference inference_core.py:273-293; 5 of the 8 interactions of a DAVIS session,
+    davis_processor.py:75-82) against the unmodified reference's results (tests/golden/update_small.npz): the argmax over the K+1
+    channels of soft probabilities with exact ties (first index wins), of a one-hot mask and of a propagated frame's own
+    probabilities, written to masks[idx] (padded) and np_masks[idx] (cropped; 100x141 frame padded unevenly to 112x144) -
+    bit-exact on the updated frame; every other frame keeps what the propagation left there."""
+    from oracle.make_golden_update import update_inputs
+    prop, fuse = nets
+    with np.load(os.path.join(golden_dir, "update_small.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    c = json.loads(str(g["config"]))
+    images, gt = O.synthetic_clip(c["t"], c["h"], c["w"], c["k"], c["seed"])
+    core = InferenceCore(prop, fuse, images, c["k"], mem_freq=c["mem_freq"], device=DEV)
+    assert tuple(core.pad) == tuple(int(v) for v in g["pad"])
+    # before any propagation: only the updated frame changes, the rest stays zero (np_masks is allocated at construction, :77-81)
+    first = core.update_mask_only(T(g["input_2"]).to(DEV), 4)
+    assert first.shape == (c["t"], c["h"], c["w"]) and first.dtype == np.uint8
+    assert np.array_equal(first[4], g["np_masks_2"][c["calls"][2]]) and int(first[:4].sum()) == 0
+    base = core.interact(gt[0], 0).copy()
+    assert mean_iou(base, g["masks_interact"], c["k"]) >= 0.999
+    done = set()
+    for n, (idx, pm) in enumerate(zip(c["calls"], update_inputs(c, T(g["input_2"])))):
+        out = core.update_mask_only(pm if n % 2 else pm.to(DEV), idx)                # host and device arguments
+        done.add(idx)
+        assert out is core.np_masks and out.dtype == np.uint8 and out.shape == (c["t"], c["h"], c["w"])
+        assert np.array_equal(out[idx], g[f"np_masks_{n}"][idx])
+        assert np.array_equal(core.masks[idx].cpu().numpy(), g[f"masks_idx_{n}"])
+        for t in range(c["t"]):
+            if t not in done:
+                assert np.array_equal(out[t], base[t])
+    assert core.propagated_frames == c["t"] - 1                                      # no propagation happened in between
 
 
 @pytest.mark.parametrize("K", [1, 3])
@@ -374,7 +409,12 @@ def test_480p_propagation_vs_oracle(nets, synthetic_states, K):
         out, ref, _ = core.interact(gt[idx], idx), ocore.interact(gt[idx], idx), o64.interact(gt[idx], idx)
         iou = mean_iou(out, ref, K)
         assert iou >= 0.999
-        ok, rec = fp64_gate(f"480p_closed_loop[K={K},interact({idx})]", core.prob, ocore.prob, o64.prob, o64.topk_margin)
+        # K=1 holds the one session of the suite with a top-k flip on the FIRST propagated frame (the fp64 run's rank-20 / 21 gap is
+        # 1.7e-4 on frame 1 and 2.0e-5 on frame 2, against ~3e-4 of fp32 score noise): one flipped neighbour moves a ~32 x 32 pixel
+        # patch (0.25 % of the frame) by up to 1e-3, so this test - and only this one - runs the tie clause at the 5e-3 quantile.
+        # What the flip cannot hide is asserted directly by test_480p_single_step_logits_vs_oracle[1] (|dlogit| < 1e-3 on identical inputs).
+        ok, rec = fp64_gate(f"480p_closed_loop[K={K},interact({idx})]", core.prob, ocore.prob, o64.prob, o64.topk_margin,
+                            tie_quantile=5e-3 if K == 1 else TIE_QUANTILE)
         assert ok, rec
 
 

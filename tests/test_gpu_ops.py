@@ -635,8 +635,7 @@ def test_memory_read_sharp_scores_and_ties(mem_precision):
     got_t, _, _ = _run_mem(mk, mv_t, qk, 20)
     ref_t = O.memory_read(mk, mv_t, qk, 20)
     assert float((got_t - ref_t).abs().max()) < 2e-4
-    assert int((idx[0] >= 160).sum()) == 0 or True            # indices stay in range
-    assert int(idx.max()) < 160 and int(idx.min()) >= 0
+    assert int(idx.max()) < 160 and int(idx.min()) >= 0                 # indices stay in range
 
 
 def test_split_keys_matches_the_cpu_definition_bitwise_and_bank_path():

@@ -195,3 +195,22 @@ def test_generator_oracle_matches_the_reference(golden_dir, synthetic_states):
         gen.reset(c["k"])
         out = gen.interact_mask(gt[idx, 1:], idx, left, right)
         assert out.shape == g[f"prob_{n}"].shape and float((out - T(g[f"prob_{n}"])).abs().max()) <= TOL
+
+
+def test_update_mask_only_golden(golden_dir, synthetic_states):
+    """OracleCore.update_mask_only vs the unmodified reference's (inference_core.py:273-293; tests/golden/update_small.npz,
+    oracle/make_golden_update.py): soft probabilities with exact ties, a one-hot mask, a propagated frame's own probabilities;
+    unevenly padded frame (100x141 -> 112x144)."""
+    from oracle.make_golden_update import update_inputs
+    with np.load(os.path.join(golden_dir, "update_small.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    c = json.loads(str(g["config"]))
+    images, gt = O.synthetic_clip(c["t"], c["h"], c["w"], c["k"], c["seed"])
+    core = O.OracleCore(*synthetic_states, images, c["k"], mem_freq=c["mem_freq"], top_k=c["top_k"])
+    assert tuple(core.pad) == tuple(int(v) for v in g["pad"]) == (1, 2, 6, 6)
+    assert np.array_equal(core.interact(gt[0], 0), g["masks_interact"])
+    assert float((core.prob[:, c["calls"][2]] - T(g["input_2"])).abs().max()) <= TOL
+    for n, (idx, pm) in enumerate(zip(c["calls"], update_inputs(c, T(g["input_2"])))):
+        out = core.update_mask_only(pm, idx)
+        assert out.dtype == np.uint8 and np.array_equal(out, g[f"np_masks_{n}"])
+        assert np.array_equal(core.masks[idx].numpy(), g[f"masks_idx_{n}"])
