@@ -7,3 +7,4 @@ constructor so the unmodified reference can be imported on CPU when golden vecto
 are generated (see oracle/make_golden.py).
 """
 from . import models  # noqa: F401
+from . import transforms  # noqa: F401  (test-time loaders: oracle/make_golden_dataset.py)
