@@ -33,13 +33,16 @@ class DAVISProcessor:
         """scr_mask: int array [h,w] of the interacted frame, -1 = no scribble, 0 = background scribble, j = object j
         (scribbles2mask's output).  davis_processor.py:52-70 -> hard aggregated mask [K+1,1,nh,nw]."""
         scr = torch.as_tensor(np.asarray(scr_mask)).to(self.device)
-        assert tuple(scr.shape) == (self.h, self.w)
+        # [h,w]: a label map of the true frame (callers that rasterise themselves); [nh,nw]: the padded canvas the reference's
+        # to_mask rasterises on (see to_mask)
+        assert tuple(scr.shape) in ((self.h, self.w), (self.nh, self.nw))
+        sh, sw = scr.shape
         with ops.on_device(self.device):
             K = self.k
             ids = torch.arange(1, K + 1, device=self.device).view(K, 1, 1)
             pos = (scr[None] == ids).float()                                     # [K,h,w]
             neg = ((scr[None] != ids) & (scr[None] != -1)).float()
-            rs = ops.dilate3x3(torch.cat([pos, neg], 0)).view(2, K, self.h, self.w)     # cv2.dilate, 3x3 ones
+            rs = ops.dilate3x3(torch.cat([pos, neg], 0)).view(2, K, sh, sw)      # cv2.dilate, 3x3 ones
             rs, _ = pad_divide_by(rs, 16, rs.shape[-2:])                         # padded AFTER the dilation, like the reference
             frame = self.processor.get_image_buffered(idx)                       # [1,3,nh,nw]
             cur = self.processor.masks[idx].to(self.device)                      # [1,nh,nw] uint8
@@ -59,7 +62,10 @@ class DAVISProcessor:
             if len(s) != 0:
                 scribble["scribbles"] = [s]
                 break
-        scr_mask = scribbles2mask(scribble, (self.h, self.w))[0]
+        # The reference pads the clip BEFORE it stores "the true dimensions" (davis_processor.py:20-32: self.h, self.w are the padded
+        # ones), so its scribble paths - normalised to [0, 1] over the true frame - are rasterised over the PADDED canvas (854 -> 864
+        # columns stretches a stroke by 1.2 %).  Results have to match the reference's, so the same canvas is used here.
+        scr_mask = scribbles2mask(scribble, (self.nh, self.nw))[0]
         return self.mask_from_scribble_mask(scr_mask, idx), idx
 
     def _advance(self, mask, idx):

@@ -8,7 +8,8 @@
 
     inference_core, davis_processor, model.propagation.prop_net, model.propagation.modules, model.fusion_net,
     model.aggregate, model.attn_network, model.s2m.s2m_network, util.tensor_util,
-    generation.fusion_generator (generate_fusion.py:16), model.fusion_model (train.py:14)
+    generation.fusion_generator (generate_fusion.py:16), model.fusion_model (train.py:14),
+    dataset.davis_test_dataset / dataset.yv_test_dataset / dataset.range_transform / dataset.onehot_util (the test-time loaders)
 
 Everything else of the reference (``interact``, ``dataset``, ``model.s2s`` ...) keeps resolving to the reference
 tree, which is appended to the package search paths of ``model`` / ``util``.
@@ -30,9 +31,13 @@ ALIASES = {
     "util.tensor_util": "mivos_amd.util.tensor_util",
     "generation.fusion_generator": "mivos_amd.generation.fusion_generator",      # generate_fusion.py:16
     "model.fusion_model": "mivos_amd.model.fusion_model",                        # train.py:14
+    "dataset.davis_test_dataset": "mivos_amd.dataset.davis_test_dataset",        # eval_interactive_davis.py:14, generate_fusion.py:16
+    "dataset.yv_test_dataset": "mivos_amd.dataset.yv_test_dataset",
+    "dataset.range_transform": "mivos_amd.dataset.range_transform",              # interact/interactive_utils.py:15 (no torchvision needed)
+    "dataset.onehot_util": "mivos_amd.dataset.onehot_util",
 }
 PACKAGES = {"model": "mivos_amd.model", "model.propagation": "mivos_amd.model.propagation", "model.s2m": "mivos_amd.model.s2m",
-            "util": "mivos_amd.util", "generation": "mivos_amd.generation"}
+            "util": "mivos_amd.util", "generation": "mivos_amd.generation", "dataset": "mivos_amd.dataset"}
 
 
 def install(reference_root=None):
