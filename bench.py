@@ -340,7 +340,11 @@ def main():
     ap.add_argument("--objects", type=int, default=None)
     ap.add_argument("--top-k", type=int, default=None)
     ap.add_argument("--mem-freq", type=int, default=5)
-    ap.add_argument("--clips", type=int, default=48, help="config 4: how many of the 474 suite clips to run (474 = all)")
+    ap.add_argument("--clips", type=int, default=474, help="config 4: how many of the 474 suite clips to run (default: all; ~4 min on one GPU)")
+    ap.add_argument("--stub-engine", action="store_true",
+                    help="PLUMBING TEST ONLY (tests/test_bench_multirank.py): config 4 with a numpy stand-in for InferenceCore, so that argument "
+                         "parsing, self-spawn, sharding, the record gather and the JSON line can be exercised with world_size 2 on a machine "
+                         "without a GPU; the line says stub_engine: true and its value is not a measurement")
     ap.add_argument("--generator", action="store_true",
                     help="config 4 as the offline fusion-data generator (generate_fusion.py:68-120): every 5th frame of a clip is a reference "
                          "frame whose masks are propagated to both ends of the clip (FusionGenerator), sharded over the ranks like the suite")
@@ -369,6 +373,10 @@ def main():
     rank, world, local = shard.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.stub_engine:
+        if args.config != 4:
+            raise SystemExit("--stub-engine is the config-4 plumbing test")
+        return bench_suite(args, torch, ops, shard, rank, world, "cpu")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     local = local % torch.cuda.device_count()      # (more ranks than GPUs only in the MIVOS_DIST_BACKEND=gloo plumbing test)
@@ -408,6 +416,7 @@ def main():
     clock, masks_first = run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, warmup, steps, args.profile_every)
     elapsed = shard.max_over_ranks(clock.t1 - clock.t0, device=dev)
     recs = shard.gather_records([dict(rank=rank, steps=steps, seconds=round(clock.t1 - clock.t0, 6))])
+    ranks_seen = shard.collective_ranks(dev)
     mem_gb = torch.cuda.max_memory_allocated() / 1e9
     full = None
     if args.config in (2, 3) and not args.no_full_session:
@@ -500,7 +509,7 @@ def main():
                            baseline_config=args.config, objects=K, frames=T, height=cfg["height"], width=cfg["width"], top_k=cfg["top_k"],
                            mem_freq=args.mem_freq, session_steps=session, sessions_timed=round(steps / session, 3),
                            prepaid_frames=0, lookahead_entries_dropped_at_t0=clock.dropped, parallelism=f"sequence-sharded x{world}"),
-               roofline=roof, full_session=full, conv_kernels=table, exact_f32=exact, hbm_peak_allocated_gb=round(mem_gb, 2), per_rank=recs)
+               roofline=roof, full_session=full, conv_kernels=table, exact_f32=exact, hbm_peak_allocated_gb=round(mem_gb, 2), per_rank=recs, **ranks_seen)
     if world == 1 and cpu_frames > 1:
         out["cpu_baseline"], out["parity"] = cpu_baseline(torch, cfg, images, gt, args.mem_freq, prop, fuse, dev, cpu_frames, args.cpu_fp64)
     else:
@@ -511,29 +520,46 @@ def main():
 def bench_suite(args, torch, ops, shard, rank, world, dev):
     """--config 4: the synthetic YouTube-VOS-like suite, split over the ranks (strong scaling)."""
     from mivos_amd import eval_suite as ES
-    from mivos_amd.inference_core import InferenceCore
-    from mivos_amd.model.fusion_net import FusionNet
-    from mivos_amd.model.propagation.prop_net import PropagationNetwork
-    from mivos_amd.util import synthetic
-    prop, fuse = PropagationNetwork(top_k=args.top_k or 50), FusionNet()
-    prop.load_state_dict(synthetic.make_prop_state(0))
-    fuse.load_state_dict(synthetic.make_fuse_state(0))
-    prop, fuse = prop.to(dev).eval(), fuse.to(dev).eval()
     specs = ES.synthetic_suite(474)[:args.clips]
-    if args.generator:
-        return bench_generator(args, torch, shard, ES, specs, prop, rank, world, dev)
+    if args.stub_engine:
+        import numpy as np
 
-    def factory(spec):
-        images, gt = synthetic.synthetic_clip_device(spec.frames, spec.height, spec.width, spec.objects, seed=spec.seed, device=dev)
-        return InferenceCore(prop, fuse, images, spec.objects, mem_profile=0, mem_freq=args.mem_freq, device=dev), gt[0]
+        class StubCore:                     # "propagates" by rolling the first mask: deterministic, world-size independent
+            def __init__(self, spec):
+                self.spec = spec
 
-    ES.run_suite([ES.ClipSpec(-1, 12, 3, 480, 853, 7)], factory, 0, 1, sync=torch.cuda.synchronize)      # warm-up clip (untimed)
-    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+            def interact(self, mask, idx):
+                return np.stack([np.roll(mask, t, axis=1) for t in range(self.spec.frames)], 0).astype(np.uint8)
+
+        def factory(spec):
+            r = np.random.RandomState(spec.seed)
+            return StubCore(spec), (r.rand(12, 20) * (spec.objects + 1)).astype(np.uint8)
+        sync = lambda: None
+    else:
+        from mivos_amd.inference_core import InferenceCore
+        from mivos_amd.model.fusion_net import FusionNet
+        from mivos_amd.model.propagation.prop_net import PropagationNetwork
+        from mivos_amd.util import synthetic
+        prop, fuse = PropagationNetwork(top_k=args.top_k or 50), FusionNet()
+        prop.load_state_dict(synthetic.make_prop_state(0))
+        fuse.load_state_dict(synthetic.make_fuse_state(0))
+        prop, fuse = prop.to(dev).eval(), fuse.to(dev).eval()
+        if args.generator:
+            return bench_generator(args, torch, shard, ES, specs, prop, rank, world, dev)
+
+        def factory(spec):
+            images, gt = synthetic.synthetic_clip_device(spec.frames, spec.height, spec.width, spec.objects, seed=spec.seed, device=dev)
+            return InferenceCore(prop, fuse, images, spec.objects, mem_profile=0, mem_freq=args.mem_freq, device=dev), gt[0]
+        sync = torch.cuda.synchronize
+
+    ES.run_suite([ES.ClipSpec(-1, 12, 3, 480, 853, 7)], factory, 0, 1, sync=sync)      # warm-up clip (untimed)
+    sync(); shard.barrier(); sync()
     t0 = time.perf_counter()
-    recs = ES.run_suite(specs, factory, rank, world, sync=torch.cuda.synchronize)
-    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+    recs = ES.run_suite(specs, factory, rank, world, sync=sync)
+    sync(); shard.barrier(); sync()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
     allrecs = shard.gather_records(recs)
+    ranks_seen = shard.collective_ranks(dev)
     if rank != 0:
         return
     s = ES.summarize(allrecs, len(specs))
@@ -545,8 +571,8 @@ def bench_suite(args, torch, ops, shard, rank, world, dev):
         metric="propagated frames/sec, YouTube-VOS-like suite sharded over the GPUs", value=round(s["frames"] / elapsed, 3), unit="frames/s",
         n_gpus=world, steps=s["frames"], warmup=11, ms_per_step=round(elapsed / s["frames"] * 1e3, 3), higher_is_better=True, scaling="strong",
         vs_baseline=None, dtype="f16x3 convolutions and memory-read affinity (fp16 hi+lo split operands, 3 fp16 MFMA products per term, fp32 accumulate)",
-        data="synthetic",
-        config=dict(workload=f"youtubevos_like_suite (BASELINE config 4): first {len(specs)} of 474 synthetic clips, lengths 5*U{{4..36}}, K~U{{1..5}}, 480x853, "
+        data="synthetic", stub_engine=bool(args.stub_engine), **ranks_seen,
+        config=dict(workload=f"youtubevos_like_suite (BASELINE config 4): {'all' if len(specs) == 474 else 'first ' + str(len(specs)) + ' of'} 474 synthetic clips, lengths 5*U{{4..36}}, K~U{{1..5}}, 480x853, "
                              f"interact(first frame); clips assigned longest-first to {world} rank(s), no data-path collective; clip generation (GPU) inside the timed region",
                     baseline_config=4, clips=len(specs), parallelism=f"sequence-sharded x{world}", suite_checksum=s["checksum"]),
         roofline=None, cpu_baseline=None, wall_seconds=round(elapsed, 3), busiest_rank_engine_seconds=round(s["busiest_rank_seconds"], 3),
@@ -663,4 +689,12 @@ def bench_generator(args, torch, shard, ES, specs, prop, rank, world, dev):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        try:
+            import torch.distributed as _dist
+            if _dist.is_available() and _dist.is_initialized():
+                _dist.destroy_process_group()
+        except Exception:
+            pass

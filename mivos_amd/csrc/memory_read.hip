@@ -1516,9 +1516,19 @@ static void launch_finalize_n(void *workspace, const float *values, int64_t valu
 // its value gather (810 MB of rows per launch at 480p, 5 objects; 82 vs 84 us, profiles/r03h_config3_kernel_stats*.csv).
 static std::mutex g_ws_mutex;
 static std::unordered_map<const void *, int> g_ws_qt;
+// Bounded: callers reallocate their workspace when the bank grows, so stale addresses accumulate in a long-lived process; when
+// the table is full it is dropped (finalize then sizes for the largest plan - the documented fallback, 84 vs 82 us).  An entry
+// exists only while the LAST select launch on that workspace succeeded: launch_select erases it first and records it after the
+// launch was accepted, so a failed select can never leave a plan that did not write the header.
+static const size_t WS_PLAN_ENTRIES = 256;
 static void remember_select_plan(const void *workspace, int qt) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
+  if (g_ws_qt.size() >= WS_PLAN_ENTRIES && !g_ws_qt.count(workspace)) g_ws_qt.clear();
   g_ws_qt[workspace] = qt;
+}
+static void forget_select_plan(const void *workspace) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  g_ws_qt.erase(workspace);
 }
 static int recall_select_plan(const void *workspace) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
@@ -1599,7 +1609,7 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
   if (int rc = check_select_args(keys, keys_ostride, qk, n_obj, n_mem, n_q, top_k, workspace, workspace_bytes)) return rc;
   const int qt = select_qt(f16, n_mem);
   const Plan pl = make_plan(n_obj, n_mem, n_q, top_k, qt);
-  remember_select_plan(workspace, qt);
+  forget_select_plan(workspace);
   SelectArgs a;
   a.keys = keys; a.keys_ostride = keys_ostride; a.qk = qk; a.header = (int *)workspace;
   a.lists = (uint64_t *)((char *)workspace + HEADER_BYTES); a.n_mem = n_mem; a.n_q = n_q;
@@ -1658,7 +1668,9 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
             f16 ? "f16x3" : "f32", qt, n_obj, (long long)n_mem, n_q, h[1], h[0], h[1] ? (double)h[0] / (double)h[1] : 0.0,
             qt == QT2 ? 24 * 32 : (f16 ? 24 * 17 : 64 * 32), h[3], h[2], h[5], h[4]);
   }
-  return check_launch("memread_select");
+  if (int rc = check_launch("memread_select")) return rc;
+  remember_select_plan(workspace, qt);
+  return MIVOS_OK;
 }
 
 extern "C" int mivos_memory_read_select(const float *keys, int64_t keys_ostride, const float *qk, int n_obj, int64_t n_mem,

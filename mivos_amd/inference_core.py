@@ -112,7 +112,8 @@ class InferenceCore:
         self.images = self.images.to(self.data_dev)
         # the default precision carries operands as fp16 hi + lo pairs: inputs beyond the fp16 range would turn into inf / NaN inside
         # the first convolution (and ReLU would silently turn those into zeros) - refuse them here (one reduction per clip)
-        if ops.CONV_PRECISION == "f16x3" and max(abs(float(v)) for v in self.images.aminmax()) >= 65504.0:
+        # (`not (amax < 65504)`: a NaN frame must be refused too - NaN compares false against everything)
+        if ops.CONV_PRECISION == "f16x3" and not (max(abs(float(v)) for v in self.images.aminmax()) < 65504.0):
             raise ops.MivosHipError("InferenceCore: |images| >= 65504 is outside the fp16 range of the f16x3 operands (INTEGRATION.md 'Limits'); "
                                     "normalise the frames (dataset/range_transform.py) or set ops.CONV_PRECISION = 'f32'")
         self.kh, self.kw = self.nh // 16, self.nw // 16
@@ -128,7 +129,7 @@ class InferenceCore:
         self._certain_k = self._certain_v = None     # [K, n, h, w, C] rows per memory position
         self.propagated_frames = 0                   # do_pass iterations so far (the bench metric)
         self._fuse_stream, self._fuse_pending = None, []
-        self._last_propagated = None                 # last frame of the most recent pass (finite-ness probe of _refresh_masks)
+        self._finite_probe = None                    # 0-dim bool tensor: "the last UNFUSED propagation output of the latest pass is finite"
 
     # ---- reference-shaped views of the certain memory -------------------------------------
     @property
@@ -240,6 +241,11 @@ class InferenceCore:
                                            values[:, :st.n_read].reshape(K, st.n_read * hw, CV), q,
                                            keys_split=None if ksplit is None else ksplit[:, :st.n_read].reshape(K, st.n_read * hw, CK))
             out = ops.aggregate(prob_k.unsqueeze(1), keep_bg=True)            # [K+1,1,nh,nw]
+            if si == len(steps) - 1:
+                # finite-ness probe (read back with the masks, _refresh_masks): the UNFUSED propagation output of the pass's last
+                # frame carries whatever overflowed before it through the bank.  It has to be taken here: FusionNet's ReLUs turn a
+                # NaN / inf input into finite numbers, so the fused probabilities of a corrupted session look clean.
+                self._finite_probe = torch.isfinite(out).all() if self._finite_probe is None else (self._finite_probe & torch.isfinite(out).all())
             if st.slot is not None:
                 self.prop_net.memorize_into(self.get_image_buffered(st.ti), out[1:],
                                             key_out=keys[:, st.slot], val_out=values[:, st.slot])
@@ -255,7 +261,6 @@ class InferenceCore:
             if step_cb is not None:
                 step_cb()
         self._join_fusion()
-        self._last_propagated = steps[-1].ti
         return closest
 
     @_on_core_device
@@ -336,14 +341,10 @@ class InferenceCore:
         l, r, t, b = self.pad
         P = self.nh * self.nw
         # The f16x3 operands are fp16 hi + lo pairs: an activation or key beyond +-65504 becomes inf and, through the memory bank,
-        # NaN in every later frame.  The last frame of the last pass carries whatever went wrong before it: one tiny reduction,
-        # read back with the masks below.
-        bad = None
-        if self._last_propagated is not None:
-            bad = ~torch.isfinite(self.prob[:, self._last_propagated]).all()
-            self._last_propagated = None
+        # NaN in every later frame.  do_pass left one 0-dim flag per pass (the unfused output of its last frame); read back here.
+        probe, self._finite_probe = self._finite_probe, None
         masks = self._argmax_and_copy(l, r, t, b, P)
-        if bad is not None and bool(bad):
+        if probe is not None and not bool(probe):
             raise ops.MivosHipError("non-finite probabilities after propagation: an activation left the fp16 range of the f16x3 operands "
                                     "(|x| >= 65504; INTEGRATION.md 'Limits')? ops.CONV_PRECISION = 'f32' runs the exact fp32 kernels")
         return masks

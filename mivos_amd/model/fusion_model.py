@@ -41,6 +41,100 @@ def _flatten_parameters(net):
     return flat, params
 
 
+# ---- torch.optim.Adam / MultiStepLR state_dict layouts (what the reference's checkpoints hold, fusion_model.py:145-157) ----------
+
+def adam_state_dict(shapes, exp_avg, exp_avg_sq, step, lr_now, lr_initial, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7):
+    """The flat Adam moments as `torch.optim.Adam(...).state_dict()`: per-parameter state {step, exp_avg, exp_avg_sq} in the order
+    of `filter(requires_grad, net.parameters())` (= named_parameters order, = the flat vector's order) + one param group."""
+    state, off = {}, 0
+    for i, shp in enumerate(shapes):
+        n = 1
+        for d in shp:
+            n *= d
+        if step > 0:                                   # torch creates a parameter's state at its first step()
+            state[i] = dict(step=torch.tensor(float(step)), exp_avg=exp_avg[off:off + n].detach().cpu().reshape(shp).clone(),
+                            exp_avg_sq=exp_avg_sq[off:off + n].detach().cpu().reshape(shp).clone())
+        off += n
+    group = dict(lr=float(lr_now), betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False, foreach=None,
+                 capturable=False, differentiable=False, fused=None, initial_lr=float(lr_initial), params=list(range(len(shapes))))
+    return dict(state=state, param_groups=[group])
+
+
+def flat_from_adam_state_dict(sd, shapes, device):
+    """Inverse of adam_state_dict for checkpoints written by torch.optim.Adam (any torch version: `step` an int or a tensor) ->
+    (exp_avg flat, exp_avg_sq flat, step)."""
+    total = 0
+    for shp in shapes:
+        n = 1
+        for d in shp:
+            n *= d
+        total += n
+    m, v = torch.zeros(total, dtype=torch.float32, device=device), torch.zeros(total, dtype=torch.float32, device=device)
+    if len(sd["param_groups"]) != 1 or len(sd["param_groups"][0]["params"]) != len(shapes):
+        raise MivosHipError("optimizer state_dict does not describe FusionNet's %d parameters in one group" % len(shapes))
+    step, off = 0, 0
+    for i, shp in zip(sd["param_groups"][0]["params"], shapes):
+        n = 1
+        for d in shp:
+            n *= d
+        st = sd["state"].get(i)
+        if st is not None:
+            if tuple(st["exp_avg"].shape) != tuple(shp):
+                raise MivosHipError(f"optimizer state of parameter {i} has shape {tuple(st['exp_avg'].shape)}, expected {tuple(shp)}")
+            m[off:off + n] = st["exp_avg"].reshape(-1).to(device=device, dtype=torch.float32)
+            v[off:off + n] = st["exp_avg_sq"].reshape(-1).to(device=device, dtype=torch.float32)
+            step = max(step, int(round(float(st["step"]))))
+        off += n
+    return m, v, step
+
+
+def multistep_state_dict(milestones, gamma, lr_initial, last_epoch):
+    """`torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma).state_dict()` after `last_epoch` scheduler steps."""
+    from collections import Counter
+    lr = lr_initial * gamma ** sum(1 for m in milestones if m <= last_epoch)
+    return dict(milestones=Counter(milestones), gamma=gamma, base_lrs=[float(lr_initial)], last_epoch=int(last_epoch), verbose=False,
+                _step_count=int(last_epoch) + 1, _get_lr_called_within_step=False, _last_lr=[float(lr)])
+
+
+class Integrator:
+    """Running means of the logged losses (reference util/log_integrator.py:10-78, the part FusionModel uses): add_dict per
+    iteration, finalize(prefix, it) averages, sums over the ranks (one reduce of a scalar per key) and hands rank 0's logger
+    `log_metrics(prefix, key, value, it)`."""
+
+    def __init__(self, logger, distributed=False, local_rank=0, world_size=1):
+        self.values, self.counts, self.hooks = {}, {}, []
+        self.logger, self.distributed, self.local_rank, self.world_size = logger, distributed, local_rank, world_size
+
+    def add_tensor(self, key, value):
+        # device scalars stay on the device until finalize(): no host synchronisation per iteration
+        v = value.detach().float().mean() if torch.is_tensor(value) else float(value)
+        self.values[key] = v if key not in self.values else self.values[key] + v
+        self.counts[key] = self.counts.get(key, 0) + 1
+
+    def add_dict(self, d):
+        for k, v in d.items():
+            self.add_tensor(k, v)
+
+    def add_hook(self, hook):
+        self.hooks.extend(hook if isinstance(hook, list) else [hook])
+
+    def reset_except_hooks(self):
+        self.values, self.counts = {}, {}
+
+    def finalize(self, prefix, it, f=None):
+        for hook in self.hooks:
+            k, v = hook(self.values)
+            self.add_tensor(k, v)
+        for k, v in self.values.items():
+            if k[:4] == "hide":
+                continue
+            avg = float(v) / self.counts[k]
+            if self.distributed:
+                avg = shard.mean_over_ranks(avg)
+            if self.logger is not None and self.local_rank == 0:
+                self.logger.log_metrics(prefix, k, avg, it, f)
+
+
 class BootstrappedSchedule:
     """losses.py:21-41: before start_warm the plain mean, then the mean of the top this_p fraction of the per-pixel losses."""
 
@@ -74,16 +168,31 @@ class FusionModel:
         self.opt_step = 0
         self.bce = BootstrappedSchedule(int(para["iterations"] * 0.2), int(para["iterations"] * 0.5))
         self.logger, self.save_path = logger, save_path
+        # logging / checkpoint cadence of the reference (fusion_model.py:31-52)
+        import time
+        self.last_time = time.time()
+        self.train_integrator = Integrator(logger, distributed=self.distributed, local_rank=local_rank, world_size=world_size)
+        self.val_integrator = Integrator(logger, distributed=self.distributed, local_rank=local_rank, world_size=world_size)
+        self.report_interval, self.save_im_interval, self.save_model_interval = 100, 500, 5000
+        if para.get("debug"):
+            self.report_interval = self.save_im_interval = 1
         self.train()
 
     # ---- modes (fusion_model.py:203-224; BN-free networks: the flags only gate the backward pass / logging) --------------
     def train(self):
         self._is_train, self._do_log = True, True
+        self.integrator = self.train_integrator
         return self
 
     def val(self):
         self._is_train, self._do_log = False, True
+        self.integrator = self.val_integrator
         return self
+
+    def finalize_val(self, it):
+        """fusion_model.py:190-192: log and reset the validation means."""
+        self.val_integrator.finalize("val", it)
+        self.val_integrator.reset_except_hooks()
 
     def test(self):
         self._is_train, self._do_log = False, False
@@ -196,7 +305,19 @@ class FusionModel:
                     wsel = torch.stack([tau, torch.full_like(tau, 1.0 / (k * B)), (k - n_gt) / n_eq / (k * B)], 1).contiguous()
                     this_p = frac
                 losses = {"total_loss": per_sample.sum() / B, "p": this_p}
+                if self._do_log:
+                    self.integrator.add_dict(losses)                   # (image dumps of the reference's logger, :99-113, are not reproduced)
             if self._is_train:
+                import time
+                if it % self.report_interval == 0 and it != 0:          # fusion_model.py:115-121
+                    if self.logger is not None:
+                        self.logger.log_scalar("train/lr", self.current_lr(), it)
+                        self.logger.log_metrics("train", "time", (time.time() - self.last_time) / self.report_interval, it)
+                    self.last_time = time.time()
+                    self.train_integrator.finalize("train", it)
+                    self.train_integrator.reset_except_hooks()
+                if it % self.save_model_interval == 0 and it != 0 and self.logger is not None:      # :123-125: a job killed mid-run keeps
+                    self.save(it)                                                                   # its last periodic checkpoint
                 dz1, dz2 = ops.fusion_loss_grad(z[0], z[1], selector, cls_gt, loss, wsel)
                 dz = torch.stack([dz1, dz2], 0).view(2 * B, H, W, 1)
                 self._backward(dz, acts)
@@ -227,9 +348,12 @@ class FusionModel:
             print("Saving has been disabled.")
             return
         os.makedirs(os.path.dirname(self.save_path), exist_ok=True)
-        torch.save({"it": it, "network": self.net.state_dict(),
-                    "optimizer": {"step": self.opt_step, "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu()},
-                    "scheduler": {"milestones": self.milestones, "gamma": self.gamma}}, self.save_path + "_checkpoint.pth")
+        # the reference's layout (fusion_model.py:152-157): torch.optim.Adam / MultiStepLR state_dicts, so either side resumes the other's run
+        shapes = [tuple(p.shape) for p in self.params]
+        torch.save({"it": it, "network": {k: v.detach().cpu() for k, v in self.net.state_dict().items()},
+                    "optimizer": adam_state_dict(shapes, self.exp_avg, self.exp_avg_sq, self.opt_step, self.current_lr(), self.lr, self.betas, self.eps,
+                                                 self.weight_decay),
+                    "scheduler": multistep_state_dict(self.milestones, self.gamma, self.lr, self.opt_step)}, self.save_path + "_checkpoint.pth")
 
     def _load_net_state(self, state):
         self.net.load_state_dict(state)
@@ -237,10 +361,22 @@ class FusionModel:
         self.net.invalidate_plan()
 
     def load_model(self, path):
-        ck = torch.load(path, map_location=self.device)
+        """Resume from a `*_checkpoint.pth` written by this class OR by the reference's FusionModel (same layout: 'network',
+        torch.optim.Adam's 'optimizer' state_dict, MultiStepLR's 'scheduler' state_dict); the private layout of this class's
+        round-3 checkpoints ({step, exp_avg, exp_avg_sq} flat) is still read."""
+        ck = torch.load(path, map_location="cpu", weights_only=False)
         self._load_net_state(ck["network"])
-        self.opt_step = ck["optimizer"]["step"]
-        self.exp_avg, self.exp_avg_sq = ck["optimizer"]["exp_avg"].to(self.device), ck["optimizer"]["exp_avg_sq"].to(self.device)
+        opt, sch = ck["optimizer"], ck.get("scheduler") or {}
+        if "param_groups" in opt:
+            self.exp_avg, self.exp_avg_sq, step = flat_from_adam_state_dict(opt, [tuple(p.shape) for p in self.params], self.device)
+            self.opt_step = int(sch.get("last_epoch", step))
+            if "base_lrs" in sch:
+                self.lr = float(sch["base_lrs"][0])
+            if "milestones" in sch:
+                self.milestones, self.gamma = sorted(sch["milestones"].elements()) if hasattr(sch["milestones"], "elements") else list(sch["milestones"]), sch.get("gamma", self.gamma)
+        else:
+            self.opt_step = opt["step"]
+            self.exp_avg, self.exp_avg_sq = opt["exp_avg"].to(self.device), opt["exp_avg_sq"].to(self.device)
         self.grad = torch.zeros_like(self.flat)
         return ck["it"]
 

@@ -19,11 +19,12 @@ ONE_CALL = os.environ.get("MIVOS_FUSION_ONE_CALL", "1") != "0"     # tuning / A-
 class FusionNet(PlanCache):
     def __init__(self):
         super().__init__()
-        self.conv1 = nn.Sequential(ConvParams(9, 32, 3, padding=1), nn.ReLU())
-        self.conv2 = nn.Sequential(ConvParams(32, 32, 3, padding=1), nn.ReLU(), ConvParams(32, 32, 3, padding=1))
-        self.conv3 = nn.Sequential(ConvParams(32, 32, 3, padding=1), nn.ReLU(), ConvParams(32, 32, 3, padding=1))
+        conv = lambda cin, cout: ConvParams(cin, cout, 3, padding=1, init="conv2d")       # trained from scratch: nn.Conv2d's default init
+        self.conv1 = nn.Sequential(conv(9, 32), nn.ReLU())
+        self.conv2 = nn.Sequential(conv(32, 32), nn.ReLU(), conv(32, 32))
+        self.conv3 = nn.Sequential(conv(32, 32), nn.ReLU(), conv(32, 32))
         self.relu = nn.ReLU()
-        self.final_conv = ConvParams(32, 1, 3, padding=1)
+        self.final_conv = conv(32, 1)
 
     def plan(self):
         if self._plan is None:

@@ -24,12 +24,19 @@ STEM_FROM_PLANES = os.environ.get("MIVOS_STEM_PLANES", "1") != "0"     # tuning 
 class ConvParams(nn.Module):
     """Holds `weight` (+ `bias`) of an nn.Conv2d; no torch forward."""
 
-    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, dilation=1):
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, dilation=1, init="he_normal"):
         super().__init__()
         self.cin, self.cout, self.k, self.stride, self.padding, self.dilation = cin, cout, k, stride, padding, dilation
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
-        nn.init.normal_(self.weight, 0.0, math.sqrt(2.0 / (cin * k * k)))
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        if init == "conv2d":
+            # nn.Conv2d.reset_parameters: what a network TRAINED FROM SCRATCH starts from in the reference (FusionNet, model/fusion_net.py)
+            nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+            if self.bias is not None:
+                bound = 1.0 / math.sqrt(cin * k * k)
+                nn.init.uniform_(self.bias, -bound, bound)
+        else:
+            nn.init.normal_(self.weight, 0.0, math.sqrt(2.0 / (cin * k * k)))
 
     def pack(self, bn=None, cin_pad=None):
         return ConvLayer.pack(self.weight, self.bias, None if bn is None else bn.tensors(), self.stride,

@@ -75,6 +75,31 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def mean_over_ranks(value):
+    """Mean of a python float over the ranks (logging: the reference's Integrator reduces every logged scalar, log_integrator.py:66-73)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t)
+    return float(t.item()) / dist.get_world_size()
+
+
+def collective_ranks(device=None):
+    """How many ranks the collective backend actually reaches: an all-reduce of ones (on `device` under nccl = RCCL over xGMI,
+    on the host under gloo).  Returned as dict(dist_backend, rccl_ranks | gloo_ranks) for the benchmark line, so that a reader
+    sees that RCCL saw N GPUs; a single-process run returns dist_backend None."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(dist_backend=None, rccl_ranks=None)
+    backend = dist.get_backend()
+    t = torch.ones(1, dtype=torch.float32, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(t)
+    n = int(round(float(t.item())))
+    if n != dist.get_world_size():
+        raise RuntimeError(f"all-reduce of ones over {dist.get_world_size()} ranks returned {n}")
+    return dict(dist_backend=backend, rccl_ranks=n if backend == "nccl" else None, **({} if backend == "nccl" else {f"{backend}_ranks": n}))
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

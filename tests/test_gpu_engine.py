@@ -538,10 +538,18 @@ def test_fp16_range_overflow_is_detected(synthetic_states):
     # a NaN that reaches the bank mid-clip is caught when the masks are read back
     core = InferenceCore(prop, fuse, images, 1, device=DEV)
     core.interact(gt[0], 0)
-    core.prob[1, 2] = float("nan")
-    core._last_propagated = 2
+    core._finite_probe = torch.isfinite(torch.tensor(float("nan"), device=DEV)).all()
     with pytest.raises(ops.MivosHipError, match="non-finite"):
         core._refresh_masks()
+    # ... and it is caught when the pass that meets it FUSES its frames (FusionNet's ReLUs would hide it in the fused probabilities):
+    # poison the certain memory's values, then interact at the other end of the clip
+    core = InferenceCore(prop, fuse, images, 1, device=DEV)
+    core.interact(gt[0], 0)
+    core._certain_v[:] = float("inf")
+    with pytest.raises(ops.MivosHipError, match="non-finite"):
+        core.interact(gt[2], 2)
+    with pytest.raises(ops.MivosHipError, match="fp16 range"):
+        InferenceCore(prop, fuse, images * float("nan"), 1, device=DEV)
     old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f32"
     try:
         out = InferenceCore(prop, fuse, images * 1e6, 1, device=DEV).interact(gt[0], 0)

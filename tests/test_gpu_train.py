@@ -187,3 +187,68 @@ def test_training_batch_size_vs_the_cpu_oracle_and_loss_decreases():
     for step in range(8):
         out = model.do_pass(dict(data), 3)
     assert float(out["losses"]["total_loss"]) < first and model.opt_step == 9
+
+
+class _Logger:
+    def __init__(self):
+        self.metrics, self.scalars = [], []
+
+    def log_metrics(self, prefix, key, value, it, f=None):
+        self.metrics.append((prefix, key, float(value), it))
+
+    def log_scalar(self, tag, value, it):
+        self.scalars.append((tag, float(value), it))
+
+
+def test_checkpoint_round_trip_and_reference_layout(tmp_path):
+    """save -> load_model resumes bit-identically; the file has the reference's layout (fusion_model.py:152-157: 'it', 'network',
+    torch.optim.Adam's 'optimizer' state_dict, MultiStepLR's 'scheduler' state_dict) so that REAL torch objects - what the reference's
+    FusionModel.load_model feeds (:171-173) - load it; a checkpoint written BY torch objects (the reference's side) resumes here; the
+    periodic save inside do_pass (:123-125) and the integrator / finalize_val surface are there."""
+    from oracle.make_golden_train import make_batch
+    data = make_batch(dict(B=2, H=64, W=64, seed=77))
+    para = dict(lr=1e-3, steps=[3], gamma=0.1, iterations=10)
+    log = _Logger()
+    a = _model(para, logger=log, save_path=str(tmp_path / "run" / "fusion"))
+    a.save_model_interval, a.report_interval = 2, 2
+    for it in range(4):
+        a.do_pass(dict(data), it)                                   # it = 2: report + periodic checkpoint (it % interval == 0 and it != 0)
+    assert os.path.isfile(str(tmp_path / "run" / "fusion_2.pth")) and os.path.isfile(str(tmp_path / "run" / "fusion_checkpoint.pth"))
+    assert [m[:2] for m in log.metrics if m[3] == 2] == [("train", "time"), ("train", "total_loss"), ("train", "p")] and log.scalars[0][0] == "train/lr"
+    a.val().do_pass(dict(data), 4)
+    a.finalize_val(4)
+    assert ("val", "total_loss") in [m[:2] for m in log.metrics] and a.val_integrator.values == {}
+    a.train()
+    a.save_checkpoint(4)
+    ck = torch.load(str(tmp_path / "run" / "fusion_checkpoint.pth"), map_location="cpu", weights_only=False)
+    assert set(ck) == {"it", "network", "optimizer", "scheduler"} and ck["it"] == 4 and set(ck["optimizer"]) == {"state", "param_groups"}
+    assert ck["scheduler"]["last_epoch"] == 4 and abs(ck["scheduler"]["_last_lr"][0] - 1e-4) < 1e-12          # milestone 3 passed
+    # (1) real torch objects (the reference's load_model) accept the file
+    ref_net = [torch.nn.Parameter(v.clone()) for k, v in ck["network"].items()]
+    opt = torch.optim.Adam(ref_net, lr=1e-3, weight_decay=1e-7)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, [3], 0.1)
+    opt.load_state_dict(ck["optimizer"])
+    sch.load_state_dict(ck["scheduler"])
+    assert abs(opt.param_groups[0]["lr"] - 1e-4) < 1e-12 and int(opt.state[ref_net[0]]["step"]) == 4
+    # (2) round trip: a fresh model resumed from the file continues exactly like the original
+    b = _model(para)
+    assert b.load_model(str(tmp_path / "run" / "fusion_checkpoint.pth")) == 4 and b.opt_step == 4
+    assert torch.equal(b.flat, a.flat) and torch.equal(b.exp_avg, a.exp_avg) and torch.equal(b.exp_avg_sq, a.exp_avg_sq)
+    oa, ob = a.do_pass(dict(data), 5), b.do_pass(dict(data), 5)
+    assert torch.equal(a.flat, b.flat) and float(oa["losses"]["total_loss"]) == float(ob["losses"]["total_loss"])
+    # (3) a checkpoint written by torch objects (reference side): torch takes one more step on the engine's gradient, saves; the engine
+    # loads it and must hold torch's state and then step like torch
+    off = 0
+    for p in ref_net:
+        p.grad = a.grad[off:off + p.numel()].view_as(p).cpu().clone()
+        off += p.numel()
+    names = list(ck["network"])
+    before = torch.cat([p.detach().reshape(-1) for p in ref_net])
+    opt.step(); sch.step()
+    torch.save({"it": 5, "network": {n: p.detach().clone() for n, p in zip(names, ref_net)}, "optimizer": opt.state_dict(), "scheduler": sch.state_dict()},
+               str(tmp_path / "ref_checkpoint.pth"))
+    c = _model(para)
+    assert c.load_model(str(tmp_path / "ref_checkpoint.pth")) == 5 and c.opt_step == 5 and abs(c.current_lr() - 1e-4) < 1e-12
+    assert torch.equal(c.flat.cpu(), torch.cat([p.detach().reshape(-1) for p in ref_net]))
+    assert torch.equal(c.exp_avg.cpu(), torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in ref_net]))
+    assert not torch.equal(before, c.flat.cpu())

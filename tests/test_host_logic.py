@@ -439,3 +439,44 @@ def test_hi_first_bound_model():
         assert dropped <= eps
         worst = max(worst, dropped / eps)
     assert worst < 0.5                                   # (and the fp32 accumulation of 128 terms, <= 1e-5 |k| |q|, fits in the margin)
+
+
+def test_fusion_checkpoint_layout_is_torch_optim_compatible():
+    """FusionModel's checkpoint halves (model/fusion_model.py: adam_state_dict / multistep_state_dict / flat_from_adam_state_dict) against
+    REAL torch.optim.Adam + MultiStepLR objects, the classes the reference's FusionModel saves and restores (fusion_model.py:152-175):
+    a torch-written state loads into the flat vectors, the flat vectors load back into torch, and both continue identically."""
+    import torch
+    from mivos_amd.model.fusion_model import adam_state_dict, flat_from_adam_state_dict, multistep_state_dict
+    from mivos_amd.util.synthetic import fuse_spec
+    shapes = [tuple(v) for v in fuse_spec().values()]
+    g = torch.Generator().manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-7)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, [2, 5], 0.1)
+    for _ in range(3):
+        for p in params:
+            p.grad = torch.randn(p.shape, generator=g)
+        opt.step()
+        sch.step()
+    m, v, step = flat_from_adam_state_dict(opt.state_dict(), shapes, "cpu")
+    assert step == 3 and m.numel() == v.numel() == sum(p.numel() for p in params) == 39905
+    off = 0
+    for i, p in enumerate(params):
+        assert torch.equal(m[off:off + p.numel()].view_as(p), opt.state[p]["exp_avg"]) and torch.equal(v[off:off + p.numel()].view_as(p), opt.state[p]["exp_avg_sq"])
+        off += p.numel()
+    ours = adam_state_dict(shapes, m, v, step, sch.get_last_lr()[0], 1e-4)
+    assert set(ours) == {"state", "param_groups"} and ours["param_groups"][0]["params"] == list(range(12)) and ours["param_groups"][0]["lr"] == sch.get_last_lr()[0]
+    clones = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    opt2 = torch.optim.Adam(clones, lr=1e-4, weight_decay=1e-7)
+    sch2 = torch.optim.lr_scheduler.MultiStepLR(opt2, [2, 5], 0.1)
+    opt2.load_state_dict(ours)
+    sch2.load_state_dict(multistep_state_dict([2, 5], 0.1, 1e-4, step))
+    assert sch2.get_last_lr() == sch.get_last_lr() and sch2.last_epoch == sch.last_epoch == 3
+    for _ in range(3):                                          # across the second milestone
+        for p, q in zip(params, clones):
+            p.grad = torch.randn(p.shape, generator=g)
+            q.grad = p.grad.clone()
+        opt.step(); opt2.step(); sch.step(); sch2.step()
+    assert all(torch.equal(p, q) for p, q in zip(params, clones)) and sch.get_last_lr() == sch2.get_last_lr()
+    fresh = adam_state_dict(shapes, m * 0, v * 0, 0, 1e-4, 1e-4)                      # before the first step: no per-parameter state, like torch
+    assert fresh["state"] == {} and flat_from_adam_state_dict(fresh, shapes, "cpu")[2] == 0
