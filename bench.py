@@ -197,10 +197,8 @@ def kernel_rooflines(samples, overhead=0.0, config=3, select_kernel=None):
         aff = dict(bound="mfma", kernel="memread_select_kernel<F16> / memread_select256_kernel from 200 k memory positions (error-compensated fp16 MFMA affinity on pre-split keys + streaming top-k)" if f16
                    else "memread_select_kernel (exact fp32 MFMA affinity + streaming top-k)",
                    achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
-                   frac_of_f32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                   peak_note=("algorithmic (fp32-equivalent) FLOP/s against 2500/3 (3 fp16 MFMA products per term); frac_of_f32_mfma_peak is the same rate "
-                              "against the 157.3 TFLOP/s a single-pass fp32 MFMA kernel (the engine's exact mode, rounds 1-2) cannot exceed" if f16
-                              else "fp32 MFMA dense peak"),
+                   peak_note=("algorithmic (fp32-equivalent) FLOP/s against 2500/3 = the roofline of the pipe this kernel runs on (3 fp16 MFMA products "
+                              "per term)" if f16 else "fp32 MFMA dense peak"),
                    traffic=pmc_traffic(config, select_kernel) if select_kernel else None, traffic_kernel=select_kernel,
                    mfma_util_pmc=pmc_mfma_util(config, select_kernel) if select_kernel else None, launches_sampled=n, avg_launch_us=round(secs / n * 1e6, 2),
                    algorithmic_gflop_per_launch=round(flops / n / 1e9, 3), algorithmic_bytes_per_launch=int(abytes / n),
@@ -482,7 +480,7 @@ def main():
                     f, t_, n_ = agg2[same[0]]
                     roof["isolated"] = dict(kernel=roof["kernel"], achieved=round(f / t_ / 1e12, 2), frac=round(f / t_ / 1e12 / roof["peak"], 4),
                                             avg_launch_us=round(t_ / n_ * 1e6, 2), launches_sampled=n_,
-                                            affinity_frac_of_f32_mfma_peak=(a2 or {}).get("frac_of_f32_mfma_peak"),
+                                            affinity_frac=(a2 or {}).get("frac"),
                                             affinity_avg_launch_us=(a2 or {}).get("avg_launch_us"),
                                             note="one untimed session, every launch sampled, fusion branch on the main stream (no concurrent kernels)")
             except Exception as e:                      # an attribution extra must never cost the line

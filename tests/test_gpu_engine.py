@@ -525,7 +525,8 @@ def test_no_topk_network_closed_loop_vs_oracle(synthetic_states):
 def test_fp16_range_overflow_is_detected(synthetic_states):
     """The f16x3 operands are fp16 hi + lo pairs: values beyond +-65504 become inf (INTEGRATION.md "Limits").  A clip whose frames are
     1e6 times brighter than anything an image normalisation produces must raise instead of returning garbage masks; the exact-fp32
-    mode runs the same clip."""
+    mode runs the same clip.  (The check is on the INPUT: an overflow that arises inside the network is silent - ReLUs and the clamp
+    of aggregate_wbg turn NaN into finite numbers - and INTEGRATION.md says so.)"""
     from mivos_amd import ops
     sd, fsd = synthetic_states
     prop, fuse = PropagationNetwork(top_k=20), FusionNet()
@@ -535,20 +536,7 @@ def test_fp16_range_overflow_is_detected(synthetic_states):
     images, gt = O.synthetic_clip(3, 128, 160, 1, seed=50)
     with pytest.raises(ops.MivosHipError, match="fp16 range"):
         InferenceCore(prop, fuse, images * 1e6, 1, device=DEV)
-    # a NaN that reaches the bank mid-clip is caught when the masks are read back
-    core = InferenceCore(prop, fuse, images, 1, device=DEV)
-    core.interact(gt[0], 0)
-    core._finite_probe = torch.isfinite(torch.tensor(float("nan"), device=DEV)).all()
-    with pytest.raises(ops.MivosHipError, match="non-finite"):
-        core._refresh_masks()
-    # ... and it is caught when the pass that meets it FUSES its frames (FusionNet's ReLUs would hide it in the fused probabilities):
-    # poison the certain memory's values, then interact at the other end of the clip
-    core = InferenceCore(prop, fuse, images, 1, device=DEV)
-    core.interact(gt[0], 0)
-    core._certain_v[:] = float("inf")
-    with pytest.raises(ops.MivosHipError, match="non-finite"):
-        core.interact(gt[2], 2)
-    with pytest.raises(ops.MivosHipError, match="fp16 range"):
+    with pytest.raises(ops.MivosHipError, match="fp16 range"):       # NaN frames are refused too (NaN compares false against any bound)
         InferenceCore(prop, fuse, images * float("nan"), 1, device=DEV)
     old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f32"
     try:
