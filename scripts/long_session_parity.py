@@ -9,7 +9,13 @@ in fp32, ~3x that in fp64); run once per round under gpurun and commit the JSON 
     python scripts/long_session_parity.py oracle --dtype fp64 --out /tmp/long64
     python scripts/long_session_parity.py engine --ref32 /tmp/long32 [--ref64 /tmp/long64] --json gpurun_out/long_session_parity.json
 
-The oracle phase writes prob_<n>.npy / masks_<n>.npy after every interaction and a `done` marker."""
+    python scripts/long_session_parity.py pack --out gpurun_in/long32        # shrink an oracle directory for shipping to the GPU box
+
+The oracle phase writes prob_<n>.npy / masks_<n>.npy after every interaction and a `done` marker.  The CPU oracles are slow (fp32 ~12 min,
+fp64 ~35 min on 8 cores) and need no GPU, so they run on the builder's machine and travel with the repo snapshot (gpurun_in/, git-ignored);
+`pack` keeps the masks at full resolution (IoU is exact) and every SUB-th pixel in both directions of the probabilities as float32 (|dprob|
+maxima and quantiles are then statistics over 1/SUB^2 of the pixels: 26 k of 415 k per frame and channel at SUB = 4; the full tensors are
+0.7 GB per interaction and precision)."""
 import argparse
 import json
 import os
@@ -51,6 +57,29 @@ def run_oracle(args, cfg):
         json.dump(dict(seconds=time.perf_counter() - t0, frames=core.propagated, threads=args.threads, dtype=args.dtype), f)
 
 
+SUB = 4
+
+
+def run_pack(args, cfg):
+    d = args.out
+    n = 0
+    while os.path.exists(os.path.join(d, f"prob_{n}.npy")):
+        p = np.load(os.path.join(d, f"prob_{n}.npy"), mmap_mode="r")
+        np.save(os.path.join(d, f"probsub_{n}.npy"), np.ascontiguousarray(p[..., ::SUB, ::SUB]).astype(np.float32))
+        np.savez_compressed(os.path.join(d, f"masksz_{n}.npz"), m=np.load(os.path.join(d, f"masks_{n}.npy")))
+        os.remove(os.path.join(d, f"prob_{n}.npy"))
+        os.remove(os.path.join(d, f"masks_{n}.npy"))
+        n += 1
+    print("packed", n, "interactions in", d, sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)) // (1 << 20), "MiB")
+
+
+def load_ref(d, n):
+    """(masks uint8 [T,H,W], prob float32 tensor, subsampled?) of interaction n from a full or a packed oracle directory."""
+    if os.path.exists(os.path.join(d, f"probsub_{n}.npy")):
+        return np.load(os.path.join(d, f"masksz_{n}.npz"))["m"], torch.from_numpy(np.load(os.path.join(d, f"probsub_{n}.npy"))), True
+    return np.load(os.path.join(d, f"masks_{n}.npy")), torch.from_numpy(np.load(os.path.join(d, f"prob_{n}.npy"))), False
+
+
 def quantiles(x, qs=(0.999, 0.9999)):
     flat = x.flatten()
     return [float(flat.kthvalue(max(1, int(round(flat.numel() * q)))).values) for q in qs]
@@ -88,11 +117,13 @@ def run_engine(args, cfg):
         masks = core.interact(gt[idx], idx)
         torch.cuda.synchronize()
         secs = time.perf_counter() - t0
-        ref_m = np.load(os.path.join(args.ref32, f"masks_{n}.npy"))
-        ref_p = torch.from_numpy(np.load(os.path.join(args.ref32, f"prob_{n}.npy")))
+        ref_m, ref_p, sub = load_ref(args.ref32, n)
         eng_p = core.prob.cpu()
-        p64 = torch.from_numpy(np.load(os.path.join(args.ref64, f"prob_{n}.npy"))) if args.ref64 else None
-        m64 = np.load(os.path.join(args.ref64, f"masks_{n}.npy")) if args.ref64 else None
+        if sub:
+            eng_p = eng_p[..., ::SUB, ::SUB].contiguous()
+        m64, p64, sub64 = load_ref(args.ref64, n) if args.ref64 else (None, None, sub)
+        assert sub64 == sub
+        out["probability_pixels_compared"] = "every %d-th pixel in both directions" % SUB if sub else "all"
         margins = json.load(open(os.path.join(args.ref32, f"margins_{n}.json")))
         frames = []
         for t in range(cfg["frames"]):
@@ -128,7 +159,7 @@ def run_engine(args, cfg):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("phase", choices=("oracle", "engine"))
+    ap.add_argument("phase", choices=("oracle", "engine", "pack"))
     ap.add_argument("--dtype", default="fp32", choices=("fp32", "fp64"))
     ap.add_argument("--out", default="/tmp/long32")
     ap.add_argument("--threads", type=int, default=32)
@@ -147,7 +178,7 @@ def main():
             cfg[k] = getattr(args, k)
     cfg["interactions"] = [0, cfg["frames"] - 1]
     torch.set_grad_enabled(False)
-    (run_oracle if args.phase == "oracle" else run_engine)(args, cfg)
+    dict(oracle=run_oracle, engine=run_engine, pack=run_pack)[args.phase](args, cfg)
 
 
 if __name__ == "__main__":
