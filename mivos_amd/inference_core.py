@@ -150,9 +150,12 @@ class InferenceCore:
             self.image_buf[idx] = self.images[:, idx].to(self.device)
         return self.image_buf[idx]
 
-    # frames encoded together on a cache miss (when the cache has room).  16 / 32 measure +1.2 % / +2 % in steady state;
-    # 8 keeps the look-ahead inside bench.py's default 8 warm-up steps, so no timed frame is encoded before the clock starts
-    QUERY_BATCH = int(os.environ.get("MIVOS_QUERY_BATCH", "8"))
+    # frames encoded together on a cache miss (when the cache has room).  Bigger batches fill the chip better (16 / 32: +1.2 % / +2 %
+    # in steady state) but every frame encoded ahead and not consumed inside a measurement window is charged to it: with 8 the driver's
+    # 20-step window encoded 24 frames (192.9 frames/s); 10 divides it and the 69-frame pass nearly evenly: 202.2 on the same box, 196.1
+    # vs 195.3 over two whole sessions (profiles/r04b_knob_ab.txt; 20 measures the same).  bench.py drops the look-ahead at t0 whatever
+    # the size, so no timed frame is ever encoded before the clock starts.
+    QUERY_BATCH = int(os.environ.get("MIVOS_QUERY_BATCH", "10"))
 
     def _encode(self, todo):
         if len(todo) == 1:

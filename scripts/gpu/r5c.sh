@@ -10,6 +10,10 @@ rm -f gpurun_out/parity_ratios.jsonl gpurun_out/teacher_forced.jsonl gpurun_out/
 timeout 1300 python -m pytest tests -m gpu -q --durations=12 > gpurun_out/r5c_pytest.log 2>&1
 echo "pytest rc $? after $(( $(date +%s) - t0 )) s"; tail -22 gpurun_out/r5c_pytest.log | cut -c1-300
 python scripts/parity_clauses.py gpurun_out/parity_ratios.jsonl > gpurun_out/r5c_parity_clauses.txt 2>&1; tail -2 gpurun_out/r5c_parity_clauses.txt
+R64=""; [ -f gpurun_in/long64/done ] && R64="--ref64 gpurun_in/long64"
+timeout 600 python scripts/long_session_parity.py engine --ref32 gpurun_in/long32 $R64 --wait 5 --json gpurun_out/r5c_long_session_parity.json > gpurun_out/r5c_long_engine.log 2>&1
+tail -3 gpurun_out/r5c_long_engine.log | cut -c1-1500
+echo "t=$(( $(date +%s) - t0 ))"
 sumline() { python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
