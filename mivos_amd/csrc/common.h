@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <atomic>
 
@@ -35,6 +36,13 @@ inline int ensure_dynamic_lds(const void *kern, size_t lds, std::atomic<uint64_t
 }
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// tuning / A-B only (MIVOS_XCD_CONTIG=0): the tile- and element-walking kernels (stem, FusionNet, upsample, maxpool) deal their work
+// round-robin over the workgroups like rounds 1-3 instead of in XCD-contiguous runs
+inline int xcd_contig() {
+  static const int v = getenv("MIVOS_XCD_CONTIG") ? atoi(getenv("MIVOS_XCD_CONTIG")) : 1;
+  return v;
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

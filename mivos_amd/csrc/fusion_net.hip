@@ -58,7 +58,7 @@ struct FuseBlockP {
   const float *wa, *wb;           // mivos_pack_weights_f16x3 rows: [32][kpad4] float4 = hi0..3 | lo0..3 (fp16), K = tap * 32 + c
   const float *sa, *sb;           // per-channel scale (2^-s of the weight pre-scaling)
   const float *ba, *bb;           // per-channel bias or NULL
-  int B, H, W, kpad4, tiles_x, tiles_y, n_tiles;
+  int B, H, W, kpad4, tiles_x, tiles_y, n_tiles, contig;
 };
 
 // 3x3 taps x 32 channels on NR pixel rows at once (rows share the weight fragments).  X*: hi / lo images of the source
@@ -210,13 +210,19 @@ __global__ __launch_bounds__(512) void fusion_resblock_kernel(const FuseBlockP p
     }
   };
 
-  int tile = blockIdx.x;
-  if (tile < p.n_tiles) { load_patch(tile); write_patch(); }      // (the grid never exceeds the tile count)
-  if (tile + (int)gridDim.x < p.n_tiles) load_patch(tile + gridDim.x);
+  // Persistent walk, XCD-contiguous: workgroup b takes ONE contiguous run of tiles and the runs of the workgroups sharing an XCD (hardware
+  // block b runs on XCD b % 8) are contiguous, so the halo rows / columns neighbouring tiles share are re-read from that XCD's L2 (or by
+  // the same CU) instead of through the fabric by another XCD (PMC FETCH_SIZE 2.5 - 5 x the input before, profiles/r04d_config3_pmc_traffic.json)
+  const int per_wg = (p.n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int tstep = p.contig ? 1 : (int)gridDim.x;               // (contig = 0: the round-robin walk of rounds 1-3, A/B only)
+  int tile = p.contig ? xcd_remap((int)blockIdx.x, (int)gridDim.x) * per_wg : (int)blockIdx.x;
+  const int tile_end = !p.contig ? p.n_tiles : (tile + per_wg < p.n_tiles ? tile + per_wg : p.n_tiles);
+  if (tile < tile_end) { load_patch(tile); write_patch(); }
+  if (tile + tstep < tile_end) load_patch(tile + tstep);
   // the two slack pixels behind the intermediate (read by lanes 30 / 31 of an output row, whose results are dropped) hold
   // whatever patch data lies there: finite fp16 numbers, and an MFMA column only ever mixes data of its own pixel
   __syncthreads();
-  for (; tile < p.n_tiles; tile += gridDim.x) {
+  for (; tile < tile_end; tile += tstep) {
     int img, y0, x0;
     tile_coords(tile, img, y0, x0);
 
@@ -282,8 +288,8 @@ __global__ __launch_bounds__(512) void fusion_resblock_kernel(const FuseBlockP p
       }
     }
     __syncthreads();                                    // every wave is done reading the intermediate
-    if (tile + (int)gridDim.x < p.n_tiles) write_patch();
-    if (tile + 2 * (int)gridDim.x < p.n_tiles) load_patch(tile + 2 * gridDim.x);
+    if (tile + tstep < tile_end) write_patch();
+    if (tile + 2 * tstep < tile_end) load_patch(tile + 2 * tstep);
     __syncthreads();
   }
 }
@@ -303,7 +309,7 @@ struct FuseConv1P {
   float cval[9];
   const float *w, *scale, *bias;   // mivos_pack_weights_f16x3 rows of conv1 (Cin padded to 16: K = tap * 16 + c, kpad4 = 48)
   float *y;                        // [B][H][W][32]
-  int B, H, W, tiles_x, tiles_y, n_tiles;
+  int B, H, W, tiles_x, tiles_y, n_tiles, contig;
 };
 
 __global__ __launch_bounds__(512) void fusion_conv1_kernel(const FuseConv1P p) {
@@ -370,11 +376,17 @@ __global__ __launch_bounds__(512) void fusion_conv1_kernel(const FuseConv1P p) {
     }
   };
 
-  int tile = blockIdx.x;
-  if (tile < p.n_tiles) { load_patch(tile); write_patch(P0); }
-  if (tile + (int)gridDim.x < p.n_tiles) load_patch(tile + gridDim.x);
+  // (see fusion_resblock_kernel) Persistent walk, XCD-contiguous: workgroup b takes ONE contiguous run of tiles and the runs of the workgroups sharing an XCD (hardware
+  // block b runs on XCD b % 8) are contiguous, so the halo rows / columns neighbouring tiles share are re-read from that XCD's L2 (or by
+  // the same CU) instead of through the fabric by another XCD (PMC FETCH_SIZE 2.5 - 5 x the input before, profiles/r04d_config3_pmc_traffic.json)
+  const int per_wg = (p.n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int tstep = p.contig ? 1 : (int)gridDim.x;               // (contig = 0: the round-robin walk of rounds 1-3, A/B only)
+  int tile = p.contig ? xcd_remap((int)blockIdx.x, (int)gridDim.x) * per_wg : (int)blockIdx.x;
+  const int tile_end = !p.contig ? p.n_tiles : (tile + per_wg < p.n_tiles ? tile + per_wg : p.n_tiles);
+  if (tile < tile_end) { load_patch(tile); write_patch(P0); }
+  if (tile + tstep < tile_end) load_patch(tile + tstep);
   __syncthreads();
-  for (int it = 0; tile < p.n_tiles; tile += gridDim.x, ++it) {
+  for (int it = 0; tile < tile_end; tile += tstep, ++it) {
     const _Float16 *Ph = P0 + (it & 1) * 2 * IMG, *Pl = Ph + IMG;
     f32x16 acc;
 #pragma unroll
@@ -411,8 +423,8 @@ __global__ __launch_bounds__(512) void fusion_conv1_kernel(const FuseConv1P p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(yp + 8 * g + 4 * h) = out[g];
     }
-    if (tile + (int)gridDim.x < p.n_tiles) write_patch(P0 + ((it + 1) & 1) * 2 * IMG);
-    if (tile + 2 * (int)gridDim.x < p.n_tiles) load_patch(tile + 2 * gridDim.x);
+    if (tile + tstep < tile_end) write_patch(P0 + ((it + 1) & 1) * 2 * IMG);
+    if (tile + 2 * tstep < tile_end) load_patch(tile + 2 * tstep);
     __syncthreads();
   }
 }
@@ -424,7 +436,7 @@ __global__ __launch_bounds__(256, 3) void fusion_head_kernel(const float *__rest
                                                           float *__restrict__ out, int H, int W, int tiles_x, int tiles_y) {
   __shared__ __attribute__((aligned(16))) float patch[HD_PR * HD_PC * HD_PITCH];
   const int tid = threadIdx.x;
-  int t = blockIdx.x;
+  int t = xcd_remap((int)blockIdx.x, (int)gridDim.x);     // neighbouring tiles (shared halo) on one XCD
   const int tx = t % tiles_x; t /= tiles_x;
   const int ty = t % tiles_y;
   const int img = t / tiles_y;
@@ -468,6 +480,7 @@ static int launch_resblock(const float *x, float *y, const mivos_fusion_layer &a
   const long long n_tiles = (long long)p.tiles_x * p.tiles_y * batch;
   if (n_tiles > 0x7fffffffLL) return fail(MIVOS_ERR_INVALID_ARGUMENT, "fusion_resblock: too many tiles");
   p.n_tiles = (int)n_tiles;
+  p.contig = xcd_contig();
   const size_t lds = (size_t)FB_LDS_HALVES * 2;
   static std::atomic<uint64_t> attr_mask{0};
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(fusion_resblock_kernel), lds, attr_mask, "fusion_resblock")) return rc;
@@ -487,6 +500,7 @@ static int launch_conv1_planes(const mivos_interleave_desc &pl, const mivos_fusi
   const long long n_tiles = (long long)p.tiles_x * p.tiles_y * batch;
   if (n_tiles > 0x7fffffffLL) return fail(MIVOS_ERR_INVALID_ARGUMENT, "fusion_conv1: too many tiles");
   p.n_tiles = (int)n_tiles;
+  p.contig = xcd_contig();
   const size_t lds = (size_t)(4 * C1_NPX * C1_PPX + 2 * 9 * 32 * C1_PW) * 2;
   static std::atomic<uint64_t> attr_mask{0};
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(fusion_conv1_kernel), lds, attr_mask, "fusion_conv1")) return rc;

@@ -1264,7 +1264,8 @@ __global__ __launch_bounds__(64) void memread_finalize_kernel(const int *__restr
   __shared__ uint32_t oi[MAX_TOPK];
   __shared__ float ow[MAX_TOPK];
   const int lane = threadIdx.x;
-  const int q = blockIdx.x, obj = blockIdx.y;
+  // neighbouring queries select overlapping value rows: one XCD (hardware block b runs on XCD b % 8) takes a contiguous range of an object's queries
+  const int q = xcd_remap((int)blockIdx.x, (int)gridDim.x), obj = blockIdx.y;
   const int stream = obj * n_qtiles + q / qt, qs = q % qt;
   // defined contents whatever the lists hold (ablation builds leave them incomplete): position 0, weight 0
   sel[lane] = pack_cand(-INFINITY, 0u); oi[lane] = 0u; ow[lane] = 0.f; wv[lane] = 0.f;

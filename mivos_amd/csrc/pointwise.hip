@@ -96,10 +96,19 @@ __global__ void upsample2x_add_kernel(const float *__restrict__ skip, int64_t sk
 // (pre-activation ResBlocks: the DMA-staged operand cannot be modified on load, so its producer applies the ReLU).
 __global__ void upsample2x_add_multi_kernel(const float *__restrict__ skip, int64_t skip_ns, const float *__restrict__ up,
                                             float *__restrict__ out, float *__restrict__ raw, float *__restrict__ rel, int64_t a_ns,
-                                            int64_t a_rs, int64_t a_ps, int N, int h, int w, int C4) {
+                                            int64_t a_rs, int64_t a_ps, int N, int h, int w, int C4, int contig) {
   const int H = 2 * h, W = 2 * w;
   const int64_t total = (int64_t)N * H * W * C4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  // Work assignment: every workgroup takes ONE contiguous run of output elements, and the runs of the workgroups that share an XCD
+  // (hardware block b runs on XCD b % 8) are contiguous too, so each XCD owns one band of image rows.  An input pixel feeds the 2 x 2 ... 3 x 3
+  // output pixels around it; with a grid-stride loop those land on all eight XCDs, whose L2s are not shared, and every XCD pulls its own
+  // copy of every input line through the fabric: rocprofv3 FETCH_SIZE 304 MB per launch against 45 MB of input (6.7 x), at which point the
+  // kernel runs at the fabric's rate, not at the rate of its 199 - 265 MB of writes (profiles/r04d_config3_pmc_traffic.json).
+  const int64_t per = (total + gridDim.x - 1) / gridDim.x;
+  const int64_t i0 = contig ? (int64_t)xcd_remap((int)blockIdx.x, (int)gridDim.x) * per : (int64_t)blockIdx.x * blockDim.x;
+  const int64_t i1 = !contig ? total : (i0 + per < total ? i0 + per : total);
+  const int64_t istep = contig ? (int64_t)blockDim.x : (int64_t)gridDim.x * blockDim.x;      // (contig = 0: grid-stride loop of rounds 1-3, A/B only)
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += istep) {
     const int c = (int)(i % C4);
     int64_t t = i / C4;
     const int x = (int)(t % W); t /= W;
@@ -128,9 +137,14 @@ __global__ void upsample2x_add_multi_kernel(const float *__restrict__ skip, int6
 
 // MaxPool 3x3 / 2 / pad 1 writing SH32 into the interior of a zero-bordered buffer (the ResNet stem's output feeds stage 1)
 __global__ void maxpool3x3s2_sh32_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t a_ns, int64_t a_rs, int64_t a_ps,
-                                         int N, int H, int W, int C4, int Ho, int Wo) {
+                                         int N, int H, int W, int C4, int Ho, int Wo, int contig) {
   const int64_t total = (int64_t)N * Ho * Wo * C4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  // contiguous run per workgroup, XCD-contiguous (see upsample2x_add_multi_kernel): the 3 x 3 / 2 windows of neighbouring outputs overlap
+  const int64_t per = (total + gridDim.x - 1) / gridDim.x;
+  const int64_t i0 = contig ? (int64_t)xcd_remap((int)blockIdx.x, (int)gridDim.x) * per : (int64_t)blockIdx.x * blockDim.x;
+  const int64_t i1 = !contig ? total : (i0 + per < total ? i0 + per : total);
+  const int64_t istep = contig ? (int64_t)blockDim.x : (int64_t)gridDim.x * blockDim.x;      // (contig = 0: grid-stride loop of rounds 1-3, A/B only)
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += istep) {
     const int c = (int)(i % C4);
     int64_t t = i / C4;
     const int ow = (int)(t % Wo); t /= Wo;
@@ -446,7 +460,7 @@ extern "C" int mivos_upsample2x_add_multi(const float *skip, int64_t skip_nstrid
   if ((raw_sh32 || relu_sh32) && ((C & 31) || ((a_nstride | a_rstride | a_pstride) & 31) || ((uintptr_t)raw_sh32 & 127) || ((uintptr_t)relu_sh32 & 127)))
     return fail(MIVOS_ERR_INVALID_ARGUMENT, "upsample2x_add_multi: SH32 outputs need C %% 32 == 0 and 128-byte aligned pixels");
   hipLaunchKernelGGL(upsample2x_add_multi_kernel, dim3(grid_for((int64_t)N * 4 * h * w * (C / 4))), dim3(256), 0, ST, skip, skip_nstride, up, out,
-                     (float *)raw_sh32, (float *)relu_sh32, a_nstride, a_rstride, a_pstride, N, h, w, C / 4);
+                     (float *)raw_sh32, (float *)relu_sh32, a_nstride, a_rstride, a_pstride, N, h, w, C / 4, xcd_contig());
   return check_launch("upsample2x_add_multi");
 }
 
@@ -456,7 +470,7 @@ extern "C" int mivos_maxpool3x3s2_sh32(const float *x, void *y_sh32, int64_t y_n
     return fail(MIVOS_ERR_INVALID_ARGUMENT, "maxpool3x3s2_sh32: bad arguments (C %% 32 != 0?)");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   hipLaunchKernelGGL(maxpool3x3s2_sh32_kernel, dim3(grid_for((int64_t)N * Ho * Wo * (C / 4))), dim3(256), 0, ST, x, (float *)y_sh32, y_nstride,
-                     y_rstride, y_pstride, N, H, W, C / 4, Ho, Wo);
+                     y_rstride, y_pstride, N, H, W, C / 4, Ho, Wo, xcd_contig());
   return check_launch("maxpool3x3s2_sh32");
 }
 

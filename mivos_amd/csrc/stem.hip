@@ -38,7 +38,7 @@ struct StemP {
   const float *scale, *bias;      // epilogue: acc * scale + bias (scale includes 1 / mult)
   float *y;                       // [N][Ho][Wo][64]
   float mult;                     // power-of-two pre-scaling of the fp16 weight split
-  int n_planes, cin, N, H, W, Ho, Wo, tiles_x, tiles_y, n_tiles;
+  int n_planes, cin, N, H, W, Ho, Wo, tiles_x, tiles_y, n_tiles, contig;
 };
 
 __global__ __launch_bounds__(512) void stem7x7s2_kernel(const StemP p) {
@@ -117,11 +117,17 @@ __global__ __launch_bounds__(512) void stem7x7s2_kernel(const StemP p) {
     }
   };
 
-  int tile = blockIdx.x;
-  if (tile < p.n_tiles) { load_patch(tile); write_patch(); }
-  if (tile + (int)gridDim.x < p.n_tiles) load_patch(tile + gridDim.x);
+  // (see fusion_resblock_kernel) Persistent walk, XCD-contiguous: workgroup b takes ONE contiguous run of tiles and the runs of the workgroups sharing an XCD (hardware
+  // block b runs on XCD b % 8) are contiguous, so the halo rows / columns neighbouring tiles share are re-read from that XCD's L2 (or by
+  // the same CU) instead of through the fabric by another XCD (PMC FETCH_SIZE 2.5 - 5 x the input before, profiles/r04d_config3_pmc_traffic.json)
+  const int per_wg = (p.n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int tstep = p.contig ? 1 : (int)gridDim.x;               // (contig = 0: the round-robin walk of rounds 1-3, A/B only)
+  int tile = p.contig ? xcd_remap((int)blockIdx.x, (int)gridDim.x) * per_wg : (int)blockIdx.x;
+  const int tile_end = !p.contig ? p.n_tiles : (tile + per_wg < p.n_tiles ? tile + per_wg : p.n_tiles);
+  if (tile < tile_end) { load_patch(tile); write_patch(); }
+  if (tile + tstep < tile_end) load_patch(tile + tstep);
   __syncthreads();
-  for (; tile < p.n_tiles; tile += gridDim.x) {
+  for (; tile < tile_end; tile += tstep) {
     f32x16 acc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
@@ -173,8 +179,8 @@ __global__ __launch_bounds__(512) void stem7x7s2_kernel(const StemP p) {
         }
     }
     __syncthreads();                                        // every wave is done reading the patch
-    if (tile + (int)gridDim.x < p.n_tiles) write_patch();
-    if (tile + 2 * (int)gridDim.x < p.n_tiles) load_patch(tile + 2 * gridDim.x);
+    if (tile + tstep < tile_end) write_patch();
+    if (tile + 2 * tstep < tile_end) load_patch(tile + 2 * tstep);
     __syncthreads();
   }
 }
@@ -201,6 +207,7 @@ extern "C" int mivos_stem7x7s2_planes(const mivos_interleave_desc *planes, int n
   const long long n_tiles = (long long)p.tiles_x * p.tiles_y * N;
   if (n_tiles > 0x7fffffffLL) return fail(MIVOS_ERR_INVALID_ARGUMENT, "stem7x7s2_planes: too many tiles");
   p.n_tiles = (int)n_tiles;
+  p.contig = xcd_contig();
   static std::atomic<uint64_t> attr_mask{0};
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(stem7x7s2_kernel), ST_LDS_BYTES, attr_mask, "stem7x7s2")) return rc;
   int dev = 0, cus = 256;

@@ -397,6 +397,25 @@ def test_maxpool_and_upsample_add():
     assert float((got - ref).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("N,h,w,C,skip_n", [(5, 60, 108, 256, 1), (3, 15, 27, 32, 3), (1, 7, 5, 64, 1), (2, 30, 54, 512, 1)])
+def test_upsample_add_acts_and_maxpool_act_vs_the_fp32_kernels(N, h, w, C, skip_n):
+    """The SH32-writing forms the decoder / encoder trunks use (mivos_upsample2x_add_multi: raw + relu Acts; mivos_maxpool3x3s2_sh32), whose
+    workgroups walk XCD-contiguous runs of the output, against the dense fp32 kernels (checked against torch above): the benchmark's decoder
+    shape, ragged sizes with fewer elements than the grid, per-sample and broadcast skip tensors.  x = hi + lo carries 22 bits."""
+    g = torch.Generator().manual_seed(N * 100 + h)
+    up = torch.randn(N, h, w, C, generator=g).to(DEV)
+    skip = torch.randn(skip_n, 2 * h, 2 * w, C, generator=g).to(DEV)
+    ref = ops.upsample2x_add(skip, up)
+    raw, rel = ops.upsample2x_add_acts(skip, up, "test.up")
+    tol = 2.0 ** -21 * float(ref.abs().max())
+    assert float((ops.to_f32(raw) - ref).abs().max()) <= tol and float((ops.to_f32(rel) - ref.clamp(min=0)).abs().max()) <= tol
+    assert float(raw.buf[:, 0].abs().max()) == 0 and float(raw.buf[:, :, 0].abs().max()) == 0 and float(raw.buf[:, -1].abs().max()) == 0     # border untouched
+    x = torch.randn(N, 2 * h, 2 * w, C, generator=g).to(DEV)
+    a = ops.maxpool3x3s2(x, act_tag="test.pool", as_act=True)
+    want = ops.maxpool3x3s2(x)
+    assert a.shape == tuple(want.shape) and float((ops.to_f32(a) - want).abs().max()) <= 2.0 ** -21 * float(want.abs().max())
+
+
 def test_resize_area_sigmoid():
     g = torch.Generator().manual_seed(2)
     x = torch.randn(3, 30, 54, generator=g)
