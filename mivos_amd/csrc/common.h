@@ -37,8 +37,13 @@ inline int ensure_dynamic_lds(const void *kern, size_t lds, std::atomic<uint64_t
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// tuning / A-B only (MIVOS_XCD_CONTIG=0): the tile- and element-walking kernels (stem, FusionNet, upsample, maxpool) deal their work
-// round-robin over the workgroups like rounds 1-3 instead of in XCD-contiguous runs
+// How the tile- / element-walking kernels deal their work to the workgroups (hardware block b runs on XCD b % 8; the eight L2s are not
+// shared): round-robin (rounds 1-3) or in XCD-contiguous runs, so that neighbouring outputs - which share input lines - meet in one L2.
+// Measured per kernel (round 4, profiles/r04e_xcd_contig_ab.txt, r04e_config3_pmc_traffic.json; fabric reads per launch / kernel time):
+//   upsample2x_add_multi 304 -> 182 MB, 77.9 -> 77.8 us;  maxpool_sh32 214 -> 204 MB, same time;  fusion_head 351 -> 267 MB, 155 -> 140 us   => level 1 (default)
+//   stem 108 -> 70 MB, 104 -> 105 us;  fusion_conv1 212 -> 73 MB but 352 -> 373 us;  fusion_resblock 663 -> 604 MB, 355 -> 374 us;
+//   memread_finalize 208 -> 201 MB, 81 -> 84 us                                                                                  => level 2 only (A/B)
+// MIVOS_XCD_CONTIG = 0 / 1 / 2 (tuning only).
 inline int xcd_contig() {
   static const int v = getenv("MIVOS_XCD_CONTIG") ? atoi(getenv("MIVOS_XCD_CONTIG")) : 1;
   return v;

@@ -433,10 +433,10 @@ __global__ __launch_bounds__(512) void fusion_conv1_kernel(const FuseConv1P p) {
 constexpr int HD_TR = 8, HD_TC = 32, HD_PR = HD_TR + 2, HD_PC = HD_TC + 2, HD_PITCH = 36;   // floats per patch pixel (32 + 4 pad)
 
 __global__ __launch_bounds__(256, 3) void fusion_head_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                                                          float *__restrict__ out, int H, int W, int tiles_x, int tiles_y) {
+                                                          float *__restrict__ out, int H, int W, int tiles_x, int tiles_y, int contig) {
   __shared__ __attribute__((aligned(16))) float patch[HD_PR * HD_PC * HD_PITCH];
   const int tid = threadIdx.x;
-  int t = xcd_remap((int)blockIdx.x, (int)gridDim.x);     // neighbouring tiles (shared halo) on one XCD
+  int t = contig ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;     // neighbouring tiles (shared halo) on one XCD
   const int tx = t % tiles_x; t /= tiles_x;
   const int ty = t % tiles_y;
   const int img = t / tiles_y;
@@ -480,7 +480,7 @@ static int launch_resblock(const float *x, float *y, const mivos_fusion_layer &a
   const long long n_tiles = (long long)p.tiles_x * p.tiles_y * batch;
   if (n_tiles > 0x7fffffffLL) return fail(MIVOS_ERR_INVALID_ARGUMENT, "fusion_resblock: too many tiles");
   p.n_tiles = (int)n_tiles;
-  p.contig = xcd_contig();
+  p.contig = xcd_contig() >= 2;
   const size_t lds = (size_t)FB_LDS_HALVES * 2;
   static std::atomic<uint64_t> attr_mask{0};
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(fusion_resblock_kernel), lds, attr_mask, "fusion_resblock")) return rc;
@@ -500,7 +500,7 @@ static int launch_conv1_planes(const mivos_interleave_desc &pl, const mivos_fusi
   const long long n_tiles = (long long)p.tiles_x * p.tiles_y * batch;
   if (n_tiles > 0x7fffffffLL) return fail(MIVOS_ERR_INVALID_ARGUMENT, "fusion_conv1: too many tiles");
   p.n_tiles = (int)n_tiles;
-  p.contig = xcd_contig();
+  p.contig = xcd_contig() >= 2;
   const size_t lds = (size_t)(4 * C1_NPX * C1_PPX + 2 * 9 * 32 * C1_PW) * 2;
   static std::atomic<uint64_t> attr_mask{0};
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(fusion_conv1_kernel), lds, attr_mask, "fusion_conv1")) return rc;
@@ -515,7 +515,7 @@ static int launch_head(const float *x, const float *w, const float *bias, float 
   const int tiles_x = cdiv(W, HD_TC), tiles_y = cdiv(H, HD_TR);
   const long long n = (long long)tiles_x * tiles_y * batch;
   if (n > 0x7fffffffLL) return fail(MIVOS_ERR_INVALID_ARGUMENT, "fusion_head: too many tiles");
-  hipLaunchKernelGGL(fusion_head_kernel, dim3((unsigned)n), dim3(256), 0, st, x, w, bias, out, H, W, tiles_x, tiles_y);
+  hipLaunchKernelGGL(fusion_head_kernel, dim3((unsigned)n), dim3(256), 0, st, x, w, bias, out, H, W, tiles_x, tiles_y, xcd_contig() >= 1);
   return check_launch("fusion_head");
 }
 

@@ -289,6 +289,7 @@ struct SelectArgs {
   uint64_t *cand;            // QT3 kernel: global candidate regions, CAND3_PER_WG entries per workgroup
   const float *kmax2;        // QT3 kernel, hi-first variant: per object, the largest squared norm of a key row (key_norm2_max_kernel)
   unsigned long long *dbg;   // profiling builds: {shader cycles, tiles} of workgroup 0 / wave 0 (NULL otherwise)
+  int contig;                // 64-query kernel: chunks dealt XCD-major (1) or in block order (0; tuning / A-B only, MIVOS_XCD_CONTIG)
 };
 
 // The finalize kernel takes the work partition from the workspace header the select launch left there (the two select
@@ -320,10 +321,12 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
   const int coff = 64 * (g & 1) + 32 * (g >> 1);
   const int lrow = tid >> 3, lc = tid & 7;           // key-tile loader: row tid>>3, float4 columns lc + 8 jj
 
-  // (Measured and dropped, round 3: dealing the chunks XCD-major - workgroup b, which runs on XCD b % 8, takes chunk
-  // (b % 8) * (n / 8) + b / 8, so that an XCD's workgroups walk overlapping parts of one object's bank - changes nothing at
-  // 480p: 283.4 vs 283.9 us, profiles/r03h_memread_microbench.txt.  The kernel is not waiting for keys there.)
-  const int chunk = (int)blockIdx.x;
+  // Chunks are dealt XCD-major: workgroup b (which runs on XCD b % 8) takes chunk (b % 8) * (n / 8) + b / 8, so that the 32 workgroups
+  // of an XCD walk neighbouring streams = the SAME object's key tiles at about the same time and one fetch through the fabric serves them
+  // all (the eight L2s are not shared).  Round 3 measured this form in isolation - 283.4 vs 283.9 us, the kernel does not wait for keys -
+  // and dropped it; but its 916 MB of fabric reads per launch (51 x the keys; 2.9 TB/s while it runs) are taken from the FusionNet
+  // kernels of the previous frame, which share the chip with it on the side stream and ARE bound by that traffic.
+  const int chunk = a.contig ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   long long t_begin = (long long)chunk * a.tiles_per_wg;
   const long long t_end = (t_begin + a.tiles_per_wg < a.total_tiles) ? t_begin + a.tiles_per_wg : a.total_tiles;
   const bool prof = a.dbg && blockIdx.x == 0;       // profiling builds only (MIVOS_MEMREAD_DBG)
@@ -1264,8 +1267,7 @@ __global__ __launch_bounds__(64) void memread_finalize_kernel(const int *__restr
   __shared__ uint32_t oi[MAX_TOPK];
   __shared__ float ow[MAX_TOPK];
   const int lane = threadIdx.x;
-  // neighbouring queries select overlapping value rows: one XCD (hardware block b runs on XCD b % 8) takes a contiguous range of an object's queries
-  const int q = xcd_remap((int)blockIdx.x, (int)gridDim.x), obj = blockIdx.y;
+  const int q = blockIdx.x, obj = blockIdx.y;      // (an XCD-contiguous query order was measured in round 4: 208 -> 201 MB of fabric reads, 81 -> 84 us; not kept)
   const int stream = obj * n_qtiles + q / qt, qs = q % qt;
   // defined contents whatever the lists hold (ablation builds leave them incomplete): position 0, weight 0
   sel[lane] = pack_cand(-INFINITY, 0u); oi[lane] = 0u; ow[lane] = 0.f; wv[lane] = 0.f;
@@ -1618,6 +1620,8 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
   a.slots = pl.slots; a.L = pl.L; a.qt = qt;
   a.cand = (uint64_t *)((char *)workspace + HEADER_BYTES + max_lists_bytes(n_obj, n_mem, n_q, top_k));
   a.kmax2 = nullptr;
+  static const int sel_xcd = getenv("MIVOS_SELECT_XCD") ? atoi(getenv("MIVOS_SELECT_XCD")) : 0;   // tuning / A-B
+  a.contig = sel_xcd;
   static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;          // profiling only
   static const int dbg = getenv("MIVOS_MEMREAD_DBG") ? atoi(getenv("MIVOS_MEMREAD_DBG")) : 0;   // profiling only: prints cycles per tile
   static unsigned long long *dbg_buf = nullptr;

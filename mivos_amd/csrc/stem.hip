@@ -207,7 +207,7 @@ extern "C" int mivos_stem7x7s2_planes(const mivos_interleave_desc *planes, int n
   const long long n_tiles = (long long)p.tiles_x * p.tiles_y * N;
   if (n_tiles > 0x7fffffffLL) return fail(MIVOS_ERR_INVALID_ARGUMENT, "stem7x7s2_planes: too many tiles");
   p.n_tiles = (int)n_tiles;
-  p.contig = xcd_contig();
+  p.contig = xcd_contig() >= 2;
   static std::atomic<uint64_t> attr_mask{0};
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(stem7x7s2_kernel), ST_LDS_BYTES, attr_mask, "stem7x7s2")) return rc;
   int dev = 0, cus = 256;
