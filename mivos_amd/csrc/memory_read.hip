@@ -324,8 +324,9 @@ __global__ __launch_bounds__(256, 1) void memread_select_kernel(const SelectArgs
   // Chunks are dealt XCD-major: workgroup b (which runs on XCD b % 8) takes chunk (b % 8) * (n / 8) + b / 8, so that the 32 workgroups
   // of an XCD walk neighbouring streams = the SAME object's key tiles at about the same time and one fetch through the fabric serves them
   // all (the eight L2s are not shared).  Round 3 measured this form in isolation - 283.4 vs 283.9 us, the kernel does not wait for keys -
-  // and dropped it; but its 916 MB of fabric reads per launch (51 x the keys; 2.9 TB/s while it runs) are taken from the FusionNet
-  // kernels of the previous frame, which share the chip with it on the side stream and ARE bound by that traffic.
+  // and dropped it.  Round 4 measured the fabric: 916 -> 376 MB of reads per launch (51 x -> 21 x the keys) at equal time in situ
+  // (353 vs 356 us, 206.2 vs 205.3 frames/s on the driver's window; profiles/r04f_select_xcd_ab.txt, r04f_config3_pmc_traffic.json):
+  // kept for the traffic - the FusionNet kernels of the previous frame share the chip and the fabric with this kernel.
   const int chunk = a.contig ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   long long t_begin = (long long)chunk * a.tiles_per_wg;
   const long long t_end = (t_begin + a.tiles_per_wg < a.total_tiles) ? t_begin + a.tiles_per_wg : a.total_tiles;
@@ -1620,7 +1621,7 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
   a.slots = pl.slots; a.L = pl.L; a.qt = qt;
   a.cand = (uint64_t *)((char *)workspace + HEADER_BYTES + max_lists_bytes(n_obj, n_mem, n_q, top_k));
   a.kmax2 = nullptr;
-  static const int sel_xcd = getenv("MIVOS_SELECT_XCD") ? atoi(getenv("MIVOS_SELECT_XCD")) : 0;   // tuning / A-B
+  static const int sel_xcd = getenv("MIVOS_SELECT_XCD") ? atoi(getenv("MIVOS_SELECT_XCD")) : 1;   // 0: block order (tuning / A-B)
   a.contig = sel_xcd;
   static const int abl = getenv("MIVOS_ABL") ? atoi(getenv("MIVOS_ABL")) : 0;          // profiling only
   static const int dbg = getenv("MIVOS_MEMREAD_DBG") ? atoi(getenv("MIVOS_MEMREAD_DBG")) : 0;   // profiling only: prints cycles per tile
