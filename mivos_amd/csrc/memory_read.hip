@@ -1455,6 +1455,8 @@ static long long q128_min() {
   }
   return v;
 }
+#include <hip/hip_version.h>
+constexpr bool Q256_TOOLCHAIN_VALIDATED = (HIP_VERSION_MAJOR == 7 && HIP_VERSION_MINOR == 2);
 static std::atomic<long long> g_q256_min{-1};     // ... and from which the 256-query plan (candidate regions in global scratch) takes over
 static long long q256_min() {
   long long v = g_q256_min.load(std::memory_order_relaxed);
@@ -1463,6 +1465,13 @@ static long long q256_min() {
     // 20 frames (163 k positions) 4.69 / 4.94 / 4.70, 30 frames 6.77 / 6.64 / 6.25, 50 frames 10.9 / 10.0 / 9.24, 200 frames
     // 41.8 / 34.5 / 28.3; 480p, 5 objects, 100 frames (162 k positions) 2.16 / 2.47 / 2.51
     v = getenv("MIVOS_MEMREAD_Q256_MIN") ? atoll(getenv("MIVOS_MEMREAD_Q256_MIN")) : 200000;
+    // The 256-query kernel (and the other two, for their key prefetch) issues global loads from inline assembly and writes their
+    // s_waitcnt vmcnt(N) by hand: correct only as long as the compiler emits no vector-memory instruction of its own inside the tile
+    // loop - a property of the code THIS toolchain generated, checked in the ISA (DESIGN / NOTEBOOK) and by the exact index-set tests on
+    // ROCm 7.2.  A library built with another hipcc keeps the kernel for callers who ask for it (mivos_memory_read_set_q256_min, the env
+    // variable above) but does not select it on its own: deep banks then run on the 128-query kernel, whose requests are counted the same
+    // way but whose candidate handling has no loads the compiler could reorder against them.
+    if (!Q256_TOOLCHAIN_VALIDATED && !getenv("MIVOS_MEMREAD_Q256_MIN")) v = 0x7fffffffffffffffLL;
     g_q256_min.store(v, std::memory_order_relaxed);
   }
   return v;
