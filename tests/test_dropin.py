@@ -30,7 +30,13 @@ def test_reference_import_lines_resolve_to_engine(tmp_path):
         from util.palette import pal_color_map
         from generation.fusion_generator import FusionGenerator            # generate_fusion.py:16
         from model.fusion_model import FusionModel                         # train.py:14
+        from dataset.davis_test_dataset import DAVISTestDataset            # eval_interactive_davis.py:14
+        from dataset.yv_test_dataset import YouTubeVOSTestDataset
+        from dataset.range_transform import im_normalization, inv_im_trans  # interact/interactive_utils.py:15
         import inspect
+        assert DAVISTestDataset.__module__ == 'mivos_amd.dataset.davis_test_dataset' and YouTubeVOSTestDataset.__module__ == 'mivos_amd.dataset.yv_test_dataset'
+        assert list(inspect.signature(DAVISTestDataset.__init__).parameters)[1:6] == ['root', 'imset', 'resolution', 'single_object', 'target_name']
+        assert list(inspect.signature(YouTubeVOSTestDataset.__init__).parameters)[1:3] == ['data_root', 'split']
         assert FusionGenerator.__module__ == 'mivos_amd.generation.fusion_generator' and FusionModel.__module__ == 'mivos_amd.model.fusion_model'
         assert list(inspect.signature(FusionGenerator.__init__).parameters)[1:] == ['prop_net', 'images', 'mem_freq']
         assert list(inspect.signature(FusionGenerator.interact_mask).parameters)[1:] == ['mask', 'idx', 'left_limit', 'right_limit']

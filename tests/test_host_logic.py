@@ -480,3 +480,23 @@ def test_fusion_checkpoint_layout_is_torch_optim_compatible():
     assert all(torch.equal(p, q) for p, q in zip(params, clones)) and sch.get_last_lr() == sch2.get_last_lr()
     fresh = adam_state_dict(shapes, m * 0, v * 0, 0, 1e-4, 1e-4)                      # before the first step: no per-parameter state, like torch
     assert fresh["state"] == {} and flat_from_adam_state_dict(fresh, shapes, "cpu")[2] == 0
+
+
+def test_xcd_contiguous_dealing_model():
+    """csrc/conv_common.h::xcd_remap (restated): hardware block b runs on XCD b % 8; the remap hands XCD x the logical indices of ONE contiguous range, is a
+    bijection for every grid size, and is the identity below 16 blocks.  The element- / tile-walking kernels (upsample, maxpool, FusionNet head, the select
+    kernel's chunks) use it so that neighbouring outputs, which read the same input lines, meet in one of the eight unshared L2s."""
+    def remap(b, n):
+        if n < 16:
+            return b
+        q, r, xcd, pos = n >> 3, n & 7, b & 7, b >> 3
+        return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + pos
+    for n in (1, 7, 15, 16, 17, 31, 130, 255, 256, 257, 2048, 8700):
+        out = [remap(b, n) for b in range(n)]
+        assert sorted(out) == list(range(n)), n
+        if n >= 16:
+            for x in range(8):
+                mine = sorted(remap(b, n) for b in range(x, n, 8))
+                assert mine == list(range(mine[0], mine[0] + len(mine))), (n, x)           # one contiguous run per XCD
+            starts = [min(remap(b, n) for b in range(x, n, 8)) for x in range(8)]
+            assert starts == sorted(starts)                                                  # XCD 0 first ... XCD 7 last
