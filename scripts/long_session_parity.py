@@ -93,6 +93,8 @@ def run_engine(args, cfg):
     from mivos_amd.util.tensor_util import compute_np_iou
     torch.set_grad_enabled(False)
     dev = "cuda:0"
+    from mivos_amd import ops
+    ops.CONV_PRECISION = args.precision
     t_wait = time.time()
     for d in (args.ref32, args.ref64):
         while d and not os.path.exists(os.path.join(d, "done")):
@@ -110,7 +112,7 @@ def run_engine(args, cfg):
     prop, fuse = prop.to(dev).eval(), fuse.to(dev).eval()
     images, gt = clip(cfg)
     core = InferenceCore(prop, fuse, images, K, mem_freq=cfg["mem_freq"], device=dev)
-    out = dict(config=cfg, oracle_fp32=json.load(open(os.path.join(args.ref32, "done"))),
+    out = dict(config=cfg, engine_precision=args.precision, oracle_fp32=json.load(open(os.path.join(args.ref32, "done"))),
                oracle_fp64=json.load(open(os.path.join(args.ref64, "done"))) if args.ref64 else None, interactions=[])
     for n, idx in enumerate(cfg["interactions"]):
         t0 = time.perf_counter()
@@ -167,6 +169,8 @@ def main():
     ap.add_argument("--ref64", default=None)
     ap.add_argument("--wait", type=int, default=1800, help="engine phase: seconds to wait for the oracle results")
     ap.add_argument("--json", default=os.path.join(ROOT, "gpurun_out", "long_session_parity.json"))
+    ap.add_argument("--precision", default="f16x3", choices=("f16x3", "f32"),
+                    help="engine phase: ops.CONV_PRECISION - f16x3 (the default engine) or f32 (every convolution and the affinity on exact fp32 MFMA)")
     ap.add_argument("--frames", type=int, default=None, help="shorter clip (smoke runs)")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
