@@ -71,6 +71,58 @@ def run_suite(specs, engine_factory, rank=0, world=1, sync=None, on_clip=None):
     return records
 
 
+# ---- the same loop over a real dataset (mivos_amd/dataset/*: the reference's test-time loaders) -----------------------------------
+
+def dataset_suite(dataset):
+    """One ClipSpec per video of a `DAVISTestDataset` / `YouTubeVOSTestDataset` from its metadata only (no frame is decoded): clip_id = the
+    dataset index, frames, objects (DAVIS: from the first annotation; YouTube-VOS: the labels of its first annotated frame - later objects
+    only shift the cost estimate), frame size after the loader's resize rule.  Feeds `run_suite(specs, dataset_factory(...), rank, world)`."""
+    specs = []
+    for i, name in enumerate(dataset.videos):
+        if hasattr(dataset, "num_frames"):                                   # DAVIS
+            h, w = dataset.shape[name][-2:]
+            specs.append(ClipSpec(i, int(dataset.num_frames[name]), max(1, int(dataset.num_objects[name])), int(h), int(w), -1))
+        else:                                                                # YouTube-VOS: short side -> 480 (yv_test_dataset.py:102-109)
+            h, w = dataset.shape[name][-2:]
+            th, tw = yv_480p_size(int(h), int(w))
+            specs.append(ClipSpec(i, len(dataset.frames[name]), 1, th, tw, -1))
+    return specs
+
+
+def first_frame_mask(gt):
+    """gt [K,T,1,H,W] one-hot objects of a loader's dictionary -> the `interact` argument of frame 0: [K+1,1,H,W], background first
+    (every pixel no object claims)."""
+    import torch
+    fg = gt[:, 0].float()                                                    # [K,1,H,W]
+    bg = (fg.sum(0, keepdim=True) < 0.5).float()
+    return torch.cat([bg, fg], 0)
+
+
+def dataset_factory(dataset, prop_net, fuse_net, device="cuda:0", mem_freq=5, core_cls=None):
+    """engine_factory for `run_suite` over a real dataset: clip `spec.clip_id` is decoded (PIL) and ingested by the loader (HIP kernels when the
+    dataset was built with device=...), an InferenceCore is built over it and the first frame's annotation becomes the interacted mask -
+    the semi-supervised protocol BASELINE config 4 names (YouTube-VOS val: first-frame masks given).  `core_cls` is injectable for CPU tests."""
+    if core_cls is None:
+        from .inference_core import InferenceCore as core_cls
+
+    def factory(spec):
+        data = dataset[spec.clip_id]
+        images, gt = data["rgb"].unsqueeze(0), data["gt"]
+        core = core_cls(prop_net, fuse_net, images, gt.shape[0], mem_profile=0, mem_freq=mem_freq, device=device)
+        return core, first_frame_mask(gt)
+    return factory
+
+
+def png_writer(dataset, out_dir, palette):
+    """`on_clip` callback of run_suite: the clip's masks as palette PNGs under <out_dir>/<video name>/ (eval_interactive_davis.py:86-94's egress)."""
+    import os
+    from . import clip_io
+
+    def on_clip(spec, masks):
+        clip_io.write_palette_png(masks, palette, os.path.join(out_dir, dataset.videos[spec.clip_id]))
+    return on_clip
+
+
 def generator_cost(n_frames, n_objects, separation):
     """Relative cost of a clip in generator mode: one two-sided propagation over the clip per reference frame."""
     return len(range(0, n_frames, separation)) * shard.clip_cost(n_frames - 1, n_objects)

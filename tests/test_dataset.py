@@ -85,3 +85,59 @@ def test_loaders_on_the_gpu_ingest_path(golden_dir, g):
     assert ds[0]["rgb"].is_cuda and ds[0]["gt"].is_cuda
     _check_davis(ds, g)
     _check_yv(YouTubeVOSTestDataset(os.path.join(golden_dir, "mini_yv"), "valid", device="cuda:0"), g, rgb_tol=2e-5)
+
+
+def test_suite_runner_over_the_loaders(golden_dir, tmp_path):
+    """eval_suite.dataset_suite / dataset_factory / png_writer: the sharded suite loop (BASELINE config 4's protocol: first-frame annotation, propagate
+    to the end) over the real loaders, with a stand-in engine on CPU: specs from metadata only, first-frame masks one-hot with background, one
+    directory of palette PNGs per video."""
+    from PIL import Image
+    from mivos_amd import eval_suite as ES
+
+    class StubCore:
+        def __init__(self, prop, fuse, images, k, mem_profile=0, mem_freq=5, device="cpu"):
+            self.t, self.k = images.shape[1], k
+            assert images.dim() == 5 and images.shape[0] == 1 and images.shape[2] == 3
+
+        def interact(self, mask, idx):
+            lab = mask[:, 0].argmax(0).numpy().astype(np.uint8)
+            return np.stack([np.roll(lab, t, axis=1) for t in range(self.t)], 0)
+
+    dav = DAVISTestDataset(os.path.join(golden_dir, "mini_davis", "trainval"), imset="2017/val.txt")
+    specs = ES.dataset_suite(dav)
+    assert [(s.clip_id, s.frames, s.objects, s.height, s.width) for s in specs] == [(0, 5, 2, 128, 157), (1, 4, 1, 128, 157)]
+    m = ES.first_frame_mask(dav[0]["gt"])
+    assert m.shape == (3, 1, 128, 157) and torch.equal(m.sum(0), torch.ones(1, 128, 157)) and float(m[0].mean()) > 0.3
+    palette = Image.open(os.path.join(golden_dir, "mini_davis", "trainval", "Annotations", "480p", "blackswan", "00000.png")).getpalette()
+    recs = ES.run_suite(specs, ES.dataset_factory(dav, None, None, device="cpu", core_cls=StubCore), on_clip=ES.png_writer(dav, str(tmp_path), palette))
+    assert ES.summarize(recs, 2)["frames"] == 4 + 3
+    first = np.array(Image.open(str(tmp_path / "blackswan" / "00000.png")))
+    want = np.array(Image.open(os.path.join(golden_dir, "mini_davis", "trainval", "Annotations", "480p", "blackswan", "00000.png")))
+    assert np.array_equal(first, want) and sorted(os.listdir(str(tmp_path / "seqb"))) == [f"{i:05d}.png" for i in range(4)]
+    yv = YouTubeVOSTestDataset(os.path.join(golden_dir, "mini_yv"), "valid")
+    ys = ES.dataset_suite(yv)
+    assert [(s.frames, s.height, s.width) for s in ys] == [(3, 480, 768)]
+    r2 = ES.run_suite(ys, ES.dataset_factory(yv, None, None, device="cpu", core_cls=StubCore))
+    assert r2[0]["frames"] == 2 and r2[0]["objects"] == 1
+
+
+@pytest.mark.gpu
+def test_suite_runner_over_the_loaders_on_the_engine(golden_dir, synthetic_states):
+    """The same loop with the real engine: mini-DAVIS through DAVISTestDataset(device='cuda:0') -> InferenceCore -> interact(first-frame annotation)."""
+    from mivos_amd import eval_suite as ES
+    from mivos_amd.model.fusion_net import FusionNet
+    from mivos_amd.model.propagation.prop_net import PropagationNetwork
+    prop, fuse = PropagationNetwork(top_k=50), FusionNet()
+    prop.load_state_dict(synthetic_states[0])
+    fuse.load_state_dict(synthetic_states[1])
+    prop, fuse = prop.to("cuda:0").eval(), fuse.to("cuda:0").eval()
+    dav = DAVISTestDataset(os.path.join(golden_dir, "mini_davis", "trainval"), imset="2017/val.txt", device="cuda:0")
+    got = {}
+    recs = ES.run_suite(ES.dataset_suite(dav), ES.dataset_factory(dav, prop, fuse, device="cuda:0"), sync=torch.cuda.synchronize,
+                        on_clip=lambda spec, masks: got.__setitem__(spec.clip_id, masks))
+    assert ES.summarize(recs, 2)["frames"] == 7
+    for i, (t, k) in enumerate(((5, 2), (4, 1))):
+        m = got[i]
+        assert m.shape == (t, 128, 157) and m.dtype == np.uint8 and set(np.unique(m)) <= set(range(k + 1))
+        want = dav[i]["gt"][:, 0, 0].cpu()                                      # frame 0 is the annotation itself
+        assert all(np.array_equal(m[0] == j + 1, want[j].numpy() > 0.5) for j in range(k))
