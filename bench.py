@@ -14,7 +14,7 @@ Workloads (fixed, `--steps/--warmup` only choose WHICH steps a
   --config 2: 480x854, 70 frames, K=1, top_k=20: session = interact(0) = 69 steps.
   --config 5: 1080x1920, K=3, `--frames` (default 1000) frames, unbounded bank (mem_freq=5 -> T grows to 200): one session.
   --config 4: synthetic YouTube-VOS-like suite (`--clips` of the 474 clips; lengths 5*U{4..36}, K~U{1..5}) sharded over
-             the ranks by mivos_amd.eval_suite; strong scaling over the fixed suite.
+             the ranks by mivos_amd.eval_suite; strong scaling over the fixed suite (default: all 474 clips, ~3.5 min on one GPU).
 Timed region: exactly `--steps` steps after `--warmup` untimed ones, bracketed by barrier + torch.cuda.synchronize(); at
 its start every query feature that was encoded ahead of its frame's turn is dropped (`prepaid_frames: 0`).  Inputs are
 resident in HBM before the clock starts.  Multi-GPU: one process per GPU; `python bench.py --gpus N` spawns its own ranks
