@@ -109,14 +109,14 @@ __global__ void upsample2x_add_multi_kernel(const float *__restrict__ skip, int6
   const int64_t i1 = !contig ? total : (i0 + per < total ? i0 + per : total);
   const int64_t istep = contig ? (int64_t)blockDim.x : (int64_t)gridDim.x * blockDim.x;      // (contig = 0: grid-stride loop of rounds 1-3, A/B only)
   for (int64_t i = i0 + threadIdx.x; i < i1; i += istep) {
-    // element order (y, x, n, c): the N objects of a pixel are neighbours in the run, so the skip tensor - ONE image broadcast over the
-    // objects in the decoder (prop_net.py:178-179 / modules.py:102) - is read once per pixel instead of once per object (it was 133 of
-    // the 182 MB this kernel pulled through the fabric per launch at 5 objects)
+    // (element order (n, y, x, c).  Round 4 also measured (y, x, n, c) - the objects of a pixel adjacent, so that the decoder's broadcast skip
+    // tensor is read once per pixel: fabric reads 182 -> 116 MB per launch, kernel time 77.8 -> 82.9 us: the kernel is bound by its 200 - 265 MB
+    // of writes, which that order scatters over the N images; not kept.)
     const int c = (int)(i % C4);
     int64_t t = i / C4;
-    const int n = (int)(t % N); t /= N;
-    const int x = (int)(t % W);
-    const int y = (int)(t / W);
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
     int y0, y1, x0, x1;
     float ly, lx;
     bilin_coord(y, 0.5f, h, y0, y1, ly);
@@ -131,7 +131,7 @@ __global__ void upsample2x_add_multi_kernel(const float *__restrict__ skip, int6
     o.y = s.y + (hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y));
     o.z = s.z + (hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z));
     o.w = s.w + (hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w));
-    if (out) reinterpret_cast<f32x4 *>(out)[(((int64_t)n * H + y) * W + x) * C4 + c] = o;
+    if (out) reinterpret_cast<f32x4 *>(out)[i] = o;
     const long long pix = (long long)n * a_ns + (long long)y * a_rs + (long long)x * a_ps;
     if (raw) store_sh32x4(raw, pix, 4 * c, o);
     if (rel) store_sh32x4(rel, pix, 4 * c, f32x4{fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f)});
