@@ -364,7 +364,10 @@ class FusionModel:
         """Resume from a `*_checkpoint.pth` written by this class OR by the reference's FusionModel (same layout: 'network',
         torch.optim.Adam's 'optimizer' state_dict, MultiStepLR's 'scheduler' state_dict); the private layout of this class's
         round-3 checkpoints ({step, exp_avg, exp_avg_sq} flat) is still read."""
-        ck = torch.load(path, map_location="cpu", weights_only=False)
+        # tensors, numbers, dicts and MultiStepLR's `collections.Counter` of milestones: loaded with the restricted unpickler
+        from collections import Counter
+        with torch.serialization.safe_globals([Counter]):
+            ck = torch.load(path, map_location="cpu", weights_only=True)
         self._load_net_state(ck["network"])
         opt, sch = ck["optimizer"], ck.get("scheduler") or {}
         if "param_groups" in opt:

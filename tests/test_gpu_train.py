@@ -220,7 +220,9 @@ def test_checkpoint_round_trip_and_reference_layout(tmp_path):
     assert ("val", "total_loss") in [m[:2] for m in log.metrics] and a.val_integrator.values == {}
     a.train()
     a.save_checkpoint(4)
-    ck = torch.load(str(tmp_path / "run" / "fusion_checkpoint.pth"), map_location="cpu", weights_only=False)
+    from collections import Counter
+    with torch.serialization.safe_globals([Counter]):
+        ck = torch.load(str(tmp_path / "run" / "fusion_checkpoint.pth"), map_location="cpu", weights_only=True)
     assert set(ck) == {"it", "network", "optimizer", "scheduler"} and ck["it"] == 4 and set(ck["optimizer"]) == {"state", "param_groups"}
     assert ck["scheduler"]["last_epoch"] == 4 and abs(ck["scheduler"]["_last_lr"][0] - 1e-4) < 1e-12          # milestone 3 passed
     # (1) real torch objects (the reference's load_model) accept the file
