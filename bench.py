@@ -339,6 +339,8 @@ def main():
     ap.add_argument("--top-k", type=int, default=None)
     ap.add_argument("--mem-freq", type=int, default=5)
     ap.add_argument("--clips", type=int, default=474, help="config 4: how many of the 474 suite clips to run (default: all; ~4 min on one GPU)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("MIVOS_SUITE_LANES", "1")),
+                    help="config 4: clips in flight per GPU, each on its own HIP stream (eval_suite.run_suite(lanes=...)); 1 = one clip at a time")
     ap.add_argument("--stub-engine", action="store_true",
                     help="PLUMBING TEST ONLY (tests/test_bench_multirank.py): config 4 with a numpy stand-in for InferenceCore, so that argument "
                          "parsing, self-spawn, sharding, the record gather and the JSON line can be exercised with world_size 2 on a machine "
@@ -529,6 +531,11 @@ def bench_suite(args, torch, ops, shard, rank, world, dev):
             def interact(self, mask, idx):
                 return np.stack([np.roll(mask, t, axis=1) for t in range(self.spec.frames)], 0).astype(np.uint8)
 
+            def interact_steps(self, mask, idx):
+                for _ in range(self.spec.frames - 1):
+                    yield
+                return self.interact(mask, idx)
+
         def factory(spec):
             r = np.random.RandomState(spec.seed)
             return StubCore(spec), (r.rand(12, 20) * (spec.objects + 1)).astype(np.uint8)
@@ -553,7 +560,8 @@ def bench_suite(args, torch, ops, shard, rank, world, dev):
     ES.run_suite([ES.ClipSpec(-1, 12, 3, 480, 853, 7)], factory, 0, 1, sync=sync)      # warm-up clip (untimed)
     sync(); shard.barrier(); sync()
     t0 = time.perf_counter()
-    recs = ES.run_suite(specs, factory, rank, world, sync=sync)
+    lane_ctx = ES.stream_lanes(dev, args.lanes) if args.lanes > 1 and not args.stub_engine else None
+    recs = ES.run_suite(specs, factory, rank, world, sync=sync, lanes=args.lanes, lane_ctx=lane_ctx)
     sync(); shard.barrier(); sync()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
     allrecs = shard.gather_records(recs)
@@ -572,7 +580,7 @@ def bench_suite(args, torch, ops, shard, rank, world, dev):
         data="synthetic", stub_engine=bool(args.stub_engine), **ranks_seen,
         config=dict(workload=f"youtubevos_like_suite (BASELINE config 4): {'all' if len(specs) == 474 else 'first ' + str(len(specs)) + ' of'} 474 synthetic clips, lengths 5*U{{4..36}}, K~U{{1..5}}, 480x853, "
                              f"interact(first frame); clips assigned longest-first to {world} rank(s), no data-path collective; clip generation (GPU) inside the timed region",
-                    baseline_config=4, clips=len(specs), parallelism=f"sequence-sharded x{world}", suite_checksum=s["checksum"]),
+                    baseline_config=4, clips=len(specs), parallelism=f"sequence-sharded x{world}", clips_in_flight_per_gpu=args.lanes, suite_checksum=s["checksum"]),
         roofline=None, cpu_baseline=None, wall_seconds=round(elapsed, 3), busiest_rank_engine_seconds=round(s["busiest_rank_seconds"], 3),
         per_rank=sorted(per_rank.values(), key=lambda r: r["rank"]),
         # multi-GPU readiness: the measured per-clip cost model (shard.clip_cost assumes frames * (1 + 0.32 * objects)) and the load

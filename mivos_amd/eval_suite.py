@@ -47,28 +47,78 @@ def mask_checksum(masks):
     return int(zlib.crc32(np.ascontiguousarray(masks).tobytes()))
 
 
-def run_suite(specs, engine_factory, rank=0, world=1, sync=None, on_clip=None):
+def run_suite(specs, engine_factory, rank=0, world=1, sync=None, on_clip=None, lanes=1, lane_ctx=None):
     """Process this rank's share of `specs`.  Returns one record per processed clip:
     dict(clip, rank, frames (propagated), objects, seconds, checksum).  `sync()` (e.g. torch.cuda.synchronize) brackets
-    the per-clip timer; `on_clip(spec, masks)` receives every result (mask egress)."""
+    the per-clip timer; `on_clip(spec, masks)` receives every result (mask egress).
+
+    lanes > 1: that many clips of this rank are in flight at once, advanced in turn frame by frame (`core.interact_steps`),
+    lane i inside the context `lane_ctx(i)` - a HIP stream per lane (`stream_lanes`), so that the under-filled launches of one
+    clip (a 480p frame of 1-5 objects fills a fraction of the 256 CUs at the 1/16-resolution layers) run beside the other's.
+    Clips stay independent - no tensor is shared between lanes but the read-only weights - and the results are bit-identical
+    to lanes = 1 (tests).  A clip's `seconds` is then its share of the rank's wall clock (its own in-flight time, scaled so
+    that the clips of a rank add up to the rank's wall clock), which keeps `summarize` and the cost-model fit meaningful."""
     parts = shard.assign_sequences([shard.clip_cost(s.frames - 1, s.objects) for s in specs], world)
-    records = []
-    for i in parts[rank]:
-        spec = specs[i]
-        core, first_mask = engine_factory(spec)
-        if sync:
-            sync()
-        t0 = time.perf_counter()
-        masks = core.interact(first_mask, 0)
-        if sync:
-            sync()
-        dt = time.perf_counter() - t0
-        if on_clip is not None:
-            on_clip(spec, masks)
-        records.append(dict(clip=spec.clip_id, rank=rank, frames=spec.frames - 1, objects=spec.objects,
-                            seconds=dt, checksum=mask_checksum(masks)))
-        del core
-    return records
+    if lanes <= 1:
+        records = []
+        for i in parts[rank]:
+            spec = specs[i]
+            core, first_mask = engine_factory(spec)
+            if sync:
+                sync()
+            t0 = time.perf_counter()
+            masks = core.interact(first_mask, 0)
+            if sync:
+                sync()
+            dt = time.perf_counter() - t0
+            if on_clip is not None:
+                on_clip(spec, masks)
+            records.append(dict(clip=spec.clip_id, rank=rank, frames=spec.frames - 1, objects=spec.objects,
+                                seconds=dt, checksum=mask_checksum(masks)))
+            del core
+        return records
+    import contextlib
+    if lane_ctx is None:
+        lane_ctx = lambda lane: contextlib.nullcontext()
+    todo = list(parts[rank])
+    records, active = {}, {}                    # lane -> [spec, core, generator, t0]
+    if sync:
+        sync()
+    t_start = time.perf_counter()
+    while todo or active:
+        for lane in range(lanes):
+            with lane_ctx(lane):
+                if lane not in active:
+                    if not todo:
+                        continue
+                    spec = specs[todo.pop(0)]
+                    core, first_mask = engine_factory(spec)
+                    active[lane] = [spec, core, core.interact_steps(first_mask, 0), time.perf_counter()]
+                spec, core, gen, t0 = active[lane]
+                try:
+                    next(gen)
+                except StopIteration as done:            # the clip's masks are on the host (interact's final copy waits for this lane's stream only)
+                    masks = done.value
+                    if on_clip is not None:
+                        on_clip(spec, masks)
+                    records[spec.clip_id] = dict(clip=spec.clip_id, rank=rank, frames=spec.frames - 1, objects=spec.objects,
+                                                 seconds=time.perf_counter() - t0, checksum=mask_checksum(masks), lanes=lanes)
+                    del active[lane]
+    if sync:
+        sync()
+    wall = time.perf_counter() - t_start
+    out = [records[specs[i].clip_id] for i in parts[rank]]
+    in_flight = sum(r["seconds"] for r in out)
+    for r in out:
+        r["seconds"] = r["seconds"] * wall / in_flight if in_flight > 0 else 0.0
+    return out
+
+
+def stream_lanes(device, lanes):
+    """`lane_ctx` of run_suite for a GPU: one HIP stream per lane (created once), entered with torch.cuda.stream."""
+    import torch
+    streams = [torch.cuda.Stream(device=device) for _ in range(lanes)]
+    return lambda lane: torch.cuda.stream(streams[lane])
 
 
 # ---- the same loop over a real dataset (mivos_amd/dataset/*: the reference's test-time loaders) -----------------------------------

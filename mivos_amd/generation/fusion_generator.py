@@ -74,7 +74,7 @@ class FusionGenerator:
         keys = torch.empty((K, total, kh, kw, CK), dtype=torch.float32, device=self.device)
         values = torch.empty((K, total, kh, kw, CV), dtype=torch.float32, device=self.device)
         keys[:, 0], values[:, 0] = key_k, key_v
-        ksplit = torch.empty_like(keys) if ops.CONV_PRECISION == "f16x3" else None
+        ksplit = torch.empty_like(keys) if ops.affinity_precision() == "f16x3" else None
         if ksplit is not None:
             ops.split_keys(keys[:, :1], ksplit[:, :1])
         for si, st in enumerate(steps):

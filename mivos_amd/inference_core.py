@@ -128,7 +128,7 @@ class InferenceCore:
         self.interacted = set()
         self._certain_k = self._certain_v = None     # [K, n, h, w, C] rows per memory position
         self.propagated_frames = 0                   # do_pass iterations so far (the bench metric)
-        self._fuse_stream, self._fuse_pending = None, []
+        self._fuse_stream = self._pass_stream = None
 
     # ---- reference-shaped views of the certain memory -------------------------------------
     @property
@@ -201,7 +201,7 @@ class InferenceCore:
     # FusionNet is HBM-bound, the encoder GEMMs are matrix-core bound.  Same kernels, same arithmetic, same results.
     FUSE_ON_SIDE_STREAM = os.environ.get("MIVOS_FUSE_SIDE_STREAM", "1") != "0"
 
-    def _fuse_async(self, closest, idx, ti, out, key_k, q):
+    def _fuse_async(self, closest, idx, ti, out, key_k, q, pending):
         main = torch.cuda.current_stream()
         if self._fuse_stream is None:
             self._fuse_stream = torch.cuda.Stream(device=self.device)
@@ -212,20 +212,22 @@ class InferenceCore:
         with torch.cuda.stream(side):
             side.wait_event(ready)
             self.prob[:, ti] = self.fuse_one_frame(closest, idx, ti, self.prob[:, ti], out, key_k, q.k16)
-        self._fuse_pending.append((out, q))           # keep the operands alive until the streams have joined
+        pending.append((out, q))                      # keep the operands alive until the streams have joined
 
-    def _join_fusion(self):
-        if self._fuse_pending:
+    def _join_fusion(self, pending):
+        if pending:
             torch.cuda.current_stream().wait_stream(self._fuse_stream)
-            self._fuse_pending = []
+            del pending[:]
 
     # ---- one propagation pass ---------------------------------------------------------------
-    def do_pass(self, key_k, key_v, idx, forward=True, step_cb=None):
-        """key_k: keys of the interacted frame, rows layout [K, h*w, 128] (used by the fusion attention)."""
+    def _pass_steps(self, plan, key_k, key_v, idx, step_cb=None):
+        """Generator over the propagated frames of one pass (`plan` = plan_pass's result): everything a frame needs is enqueued
+        on the CURRENT HIP stream, then the generator yields - nothing in a step waits for the GPU, so a driver can advance
+        several passes (of this core: `interact`, or of other cores: eval_suite.run_suite(lanes=2)) in turn, each under its own
+        stream, and the chip overlaps their under-filled launches (one 480p frame of five objects fills a quarter of the CUs
+        at the 30 x 54 layers).  The fusion branch is joined into the pass's stream when the generator finishes."""
+        closest, total, steps = plan
         nc = self._certain_k.shape[1]
-        closest, total, steps = plan_pass(self.t, self.interacted, idx, forward, self.mem_freq, nc)
-        if not steps:
-            return closest
         K, kh, kw = self.k, self.kh, self.kw
         keys = torch.empty((K, total, kh, kw, CK), dtype=torch.float32, device=self.device)
         values = torch.empty((K, total, kh, kw, CV), dtype=torch.float32, device=self.device)
@@ -233,10 +235,11 @@ class InferenceCore:
         # the affinity kernel streams keys pre-split into fp16 hi/lo pairs (ops.split_keys): a second bank of the same size,
         # every slot converted once when it is written
         # (f16x3 only: the exact-fp32 verification mode streams the fp32 rows themselves)
-        ksplit = torch.empty_like(keys) if ops.CONV_PRECISION == "f16x3" else None
+        ksplit = torch.empty_like(keys) if ops.affinity_precision() == "f16x3" else None
         if ksplit is not None:
             ops.split_keys(keys[:, :nc], ksplit[:, :nc])
         hw = kh * kw
+        pending = []
         for si, st in enumerate(steps):
             q = self._query(st.ti, upcoming=[s2.ti for s2 in steps[si + 1:si + self.QUERY_BATCH]])
             prob_k = self.prop_net.segment(keys[:, :st.n_read].reshape(K, st.n_read * hw, CK),
@@ -249,7 +252,7 @@ class InferenceCore:
                 if ksplit is not None:
                     ops.split_keys(keys[:, st.slot], ksplit[:, st.slot])
             if st.fuse and self.FUSE_ON_SIDE_STREAM and self.result_dev == self.device:
-                self._fuse_async(closest, idx, st.ti, out, key_k, q)
+                self._fuse_async(closest, idx, st.ti, out, key_k, q, pending)
             else:
                 if st.fuse:
                     out = self.fuse_one_frame(closest, idx, st.ti, self.prob[:, st.ti], out, key_k, q.k16)
@@ -257,8 +260,47 @@ class InferenceCore:
             self.propagated_frames += 1
             if step_cb is not None:
                 step_cb()
-        self._join_fusion()
-        return closest
+            yield st.ti
+        self._join_fusion(pending)
+
+    def do_pass(self, key_k, key_v, idx, forward=True, step_cb=None):
+        """key_k: keys of the interacted frame, rows layout [K, h*w, 128] (used by the fusion attention)."""
+        plan = plan_pass(self.t, self.interacted, idx, forward, self.mem_freq, self._certain_k.shape[1])
+        for _ in self._pass_steps(plan, key_k, key_v, idx, step_cb=step_cb):
+            pass
+        return plan[0]
+
+    # The forward and the backward pass of an interaction never exchange data (reference inference_core.py:255-256: two do_pass calls
+    # over disjoint frame ranges that only READ the certain memory): with everything resident in HBM they advance in turn, frame
+    # by frame, on two HIP streams.  Same kernels, same inputs, same results; MIVOS_CONCURRENT_PASSES=0 runs them one after the other.
+    CONCURRENT_PASSES = os.environ.get("MIVOS_CONCURRENT_PASSES", "1") != "0"
+
+    def _run_passes(self, rows, key_v, idx, step_cb=None):
+        nc = self._certain_k.shape[1]
+        plans = [plan_pass(self.t, self.interacted, idx, fwd, self.mem_freq, nc) for fwd in (True, False)]
+        plans = [p for p in plans if p[2]]
+        # (a clip longer than the query cache may flush it mid-interaction: a cached feature tensor freed on one stream while the other
+        # pass still reads it - such clips keep the sequential order)
+        if len(plans) < 2 or not self.CONCURRENT_PASSES or self.result_dev != self.device or self.t > self.q_buf_size:
+            for p in plans:
+                for _ in self._pass_steps(p, rows, key_v, idx, step_cb=step_cb):
+                    pass
+            return
+        main = torch.cuda.current_stream()
+        if self._pass_stream is None:
+            self._pass_stream = torch.cuda.Stream(device=self.device)
+        side = self._pass_stream
+        side.wait_stream(main)                                   # the interacted frame's keys / values / difference maps
+        lanes = [(main, self._pass_steps(plans[0], rows, key_v, idx, step_cb=step_cb)),
+                 (side, self._pass_steps(plans[1], rows, key_v, idx, step_cb=step_cb))]
+        for t in (rows, key_v):
+            t.record_stream(side)
+        while lanes:
+            for lane in list(lanes):
+                with torch.cuda.stream(lane[0]):
+                    if next(lane[1], None) is None:
+                        lanes.remove(lane)
+        main.wait_stream(side)
 
     @_on_core_device
     def fuse_logits(self, tc, tr, ti, prev_mask, curr_mask, mk16, qk16):
@@ -298,10 +340,9 @@ class InferenceCore:
         self._neg16 = ops.area_pool16(self.neg_mask_diff[1:].reshape(K, self.nh, self.nw)).view(K, -1)
 
     # ---- public entry points ------------------------------------------------------------------
-    @_on_core_device
-    def interact(self, mask, idx, total_cb=None, step_cb=None):
-        """mask: one-hot [K+1,1,H,W] (background first) of frame idx.  Propagates both ways from idx,
-        fusing with earlier results between interacted frames.  Returns uint8 [T,H,W]."""
+    def _begin_interaction(self, mask, idx, total_cb=None):
+        """Everything of `interact` before the passes (reference :219-253): register the frame, difference maps against the previous
+        result, memorise the interacted frame into the certain memory.  Returns (key rows [K, h*w, 128], values) of that frame."""
         self.interacted.add(idx)
         mask = mask.to(self.device).float()
         mask, _ = pad_divide_by(mask, 16, mask.shape[-2:])
@@ -323,11 +364,29 @@ class InferenceCore:
             back = max([ti for ti in self.interacted if ti < idx] + [-1])
             if front - back - 2 > 0:
                 total_cb(front - back - 2)
+        return key_k.reshape(K, self.kh * self.kw, CK), key_v
 
-        rows = key_k.reshape(K, self.kh * self.kw, CK)
-        self.do_pass(rows, key_v, idx, True, step_cb=step_cb)
-        self.do_pass(rows, key_v, idx, False, step_cb=step_cb)
+    @_on_core_device
+    def interact(self, mask, idx, total_cb=None, step_cb=None):
+        """mask: one-hot [K+1,1,H,W] (background first) of frame idx.  Propagates both ways from idx,
+        fusing with earlier results between interacted frames.  Returns uint8 [T,H,W]."""
+        rows, key_v = self._begin_interaction(mask, idx, total_cb)
+        self._run_passes(rows, key_v, idx, step_cb=step_cb)
         return self._refresh_masks()
+
+    def interact_steps(self, mask, idx, total_cb=None, step_cb=None):
+        """`interact` as a generator: yields after every propagated frame with that frame's work enqueued on the CURRENT HIP stream
+        and nothing waited for; when it is exhausted the result is in `np_masks` (and is the StopIteration value).  A driver that
+        advances the generators of several cores in turn, each under its own stream (eval_suite.run_suite(lanes=2)), overlaps
+        their launches on the chip.  The two passes of one interaction run one after the other here."""
+        with torch.cuda.device(self.device):
+            rows, key_v = self._begin_interaction(mask, idx, total_cb)
+            nc = self._certain_k.shape[1]
+            for fwd in (True, False):
+                plan = plan_pass(self.t, self.interacted, idx, fwd, self.mem_freq, nc)
+                if plan[2]:
+                    yield from self._pass_steps(plan, rows, key_v, idx, step_cb=step_cb)
+            return self._refresh_masks()
 
     REFRESH_CHUNK_BYTES = 1 << 30     # host-resident results (mem_profile 2/3): probabilities visit the GPU in chunks
 

@@ -274,7 +274,7 @@ class FusionModel:
 
     # ---- one iteration (fusion_model.py:54-131) ----------------------------------------------------------------------------
     def do_pass(self, data, it=0):
-        with ops.on_device(self.device), torch.no_grad():
+        with ops.on_device(self.device), torch.no_grad(), ops.single_stream_region():
             d = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in data.items()}
             im = d["rgb"].float().contiguous()
             B, _, H, W = im.shape

@@ -34,6 +34,7 @@ class FusionNet(PlanCache):
                 self._plan = (self.conv1[0].pack(cin_pad=16), self.conv2[0].pack(), self.conv2[2].pack(),
                               self.conv3[0].pack(), self.conv3[2].pack(), self.final_conv.pack())
                 self._stamp_plan()
+                ops.publish_constants()          # read by launches on every stream from here on
         return self._plan
 
     def run(self, x, layered=False):

@@ -134,6 +134,7 @@ class PropagationNetwork(PlanCache):
                                   kv_m=self.kv_m_f16.compile(), kv_q=self.kv_q_f16.compile(),
                                   dec=self.decoder.compile())
                 self._stamp_plan()
+                ops.publish_constants()          # read by launches on every stream from here on
         return self._plan
 
     # ---- internal fast path (NHWC) ------------------------------------------------------

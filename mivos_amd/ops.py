@@ -5,6 +5,7 @@ one call into libmivos_hip.so with raw device pointers.  Activations are fp32 NH
 ``[N, H, W, C]`` whose channel axis has stride 1; channel slices / batch-strided views (memory-bank
 slots) are passed as strides, never copied.  CPU tensors are rejected: there is no fallback.
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -16,6 +17,13 @@ _checked_devices = set()
 # "f16x3": error-compensated fp16 MFMA convolutions (3 products per term, fp32-class accuracy, 5.3x the
 # fp32-MFMA rate); "f32": exact fp32 MFMA everywhere (the verification path).
 CONV_PRECISION = "f16x3"
+AFFINITY_PRECISION = None    # None: the memory-read affinity follows CONV_PRECISION; "f32" / "f16x3" pin it (diagnostics: which arithmetic a closed-loop deviation comes from)
+
+
+def affinity_precision():
+    return AFFINITY_PRECISION or CONV_PRECISION
+
+
 SPLITK_WORKSPACE_BYTES = 64 << 20      # scratch handed to mivos_conv2d_fused for split-K partial tiles
 # bench.py sets this to a list to time every conv launch with HIP events on the launch stream:
 # entries (kernel variant [+10 for the f16x3 back-end], algorithmic FLOPs = 2*M*Cout*KH*KW*Cin, start event, end event)
@@ -47,6 +55,29 @@ def on_device(t):
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+_PUBLISH = [True]
+
+
+@contextlib.contextmanager
+def single_stream_region():
+    """Inside: `publish_constants` is a no-op.  For code that re-packs weights every iteration and runs on ONE stream (the FusionNet
+    training step repacks after every optimiser update): stream order alone covers it."""
+    old, _PUBLISH[0] = _PUBLISH[0], False
+    try:
+        yield
+    finally:
+        _PUBLISH[0] = old
+
+
+def publish_constants():
+    """Called once after device-resident constants (packed weights, folded BN vectors, compiled plans) were produced by launches on the
+    current stream: waits for the device, so that launches on ANY stream may read them afterwards without a stream dependency (two
+    passes / two clips advance on two streams: inference_core.InferenceCore._run_passes, eval_suite.run_suite(lanes=2)).  A one-time
+    cost per layer and process (first use), never inside a steady-state step."""
+    if _PUBLISH[0]:
+        torch.cuda.synchronize()
 
 
 # LDS-DMA convolutions address their (zero-bordered) input with 32-bit buffer offsets: one tensor < 2 GB
@@ -95,6 +126,7 @@ class ConvLayer:
             w = self.w.new_zeros((16, 1, 1, self.cin))
             w[:9, 0, 0] = self.w[0].reshape(9, self.cin)
             self.proj = ConvLayer(w, None, None, 1, 0)
+            publish_constants()
         return self.proj
 
     def slice_cin(self, c0, c1, keep_bias):
@@ -119,6 +151,7 @@ class ConvLayer:
             self.mult16, sc = self._f16x3_scale()
             if self.scale16 is None:
                 self.scale16 = sc
+            publish_constants()
         return self.mult16, self.scale16
 
     def dma(self):
@@ -132,6 +165,7 @@ class ConvLayer:
             self.wdma = wd
             if self.scale16 is None:
                 self.scale16 = scale16
+            publish_constants()
         return self.wdma, self.scale16
 
     def f16x3(self):
@@ -145,6 +179,7 @@ class ConvLayer:
             w16 = torch.empty(self.cout * kpad * 4, dtype=torch.uint8, device=self.w.device)
             check(_lib.load().mivos_pack_weights_f16x3(self.w.data_ptr(), w16.data_ptr(), self.cout, self.k, self.k, self.cin, mult, _stream()))
             self.w16, self.scale16 = w16, scale16
+            publish_constants()
         return self.w16, self.scale16
 
     @staticmethod
@@ -626,7 +661,7 @@ STREAMING_MAX_TOP_K = 64     # csrc/memory_read.hip: candidate lists of the stre
 def _memread_select(lib, keys, ko, keys_split, qk, k, n_mem, n_q, top_k, ws):
     """The affinity + streaming top-k launch in the engine's precision: "f16x3" streams pre-split keys (the caller's split
     bank, or a conversion of `keys` into scratch when there is none), "f32" the fp32 rows through the exact fp32 MFMA kernel."""
-    if CONV_PRECISION == "f32":
+    if affinity_precision() == "f32":
         check(lib.mivos_memory_read_select(keys.data_ptr(), ko, qk.data_ptr(), k, n_mem, n_q, top_k, ws.data_ptr(), ws.numel(), _stream()))
         return
     if keys_split is None:

@@ -213,6 +213,36 @@ def make_s2m_state(seed=0, calib="golden"):
     return sd
 
 
+def condition_state(sd, key_gain=1.0, logit_gain=1.0, mask_gain=1.0):
+    """Post-hoc gains on a PropagationNetwork state dict (returns a new dict; `sd` is not modified): `key_gain` scales both
+    key projections (affinity x key_gain^2: sharper top-k softmax), `logit_gain` the decoder's last layer (mask logits),
+    `mask_gain` the stem weights of the mask / "others" input channels of the memory encoder (feedback gain).  Used by the
+    closed-loop parity fixtures (scripts/studies/fixture_conditioning.py, scripts/long_session_parity.py); gains of 1 return
+    the golden weights bit for bit."""
+    out = OrderedDict((k, v.clone()) for k, v in sd.items())
+    if key_gain != 1.0:
+        for kv in ("kv_m_f16.key_proj", "kv_q_f16.key_proj"):
+            out[kv + ".weight"] = out[kv + ".weight"] * float(key_gain)
+            out[kv + ".bias"] = out[kv + ".bias"] * float(key_gain)
+    if logit_gain != 1.0:
+        out["decoder.pred.weight"] = out["decoder.pred.weight"] * float(logit_gain)
+        out["decoder.pred.bias"] = out["decoder.pred.bias"] * float(logit_gain)
+    if mask_gain != 1.0:
+        w = out["mask_rgb_encoder.conv1.weight"].clone()
+        w[:, 3:] *= float(mask_gain)
+        out["mask_rgb_encoder.conv1.weight"] = w
+    return out
+
+
+def condition_fuse_state(fsd, logit_gain=1.0):
+    """`condition_state` for FusionNet: `logit_gain` scales final_conv (the fused mask logits)."""
+    out = OrderedDict((k, v.clone()) for k, v in fsd.items())
+    if logit_gain != 1.0:
+        out["final_conv.weight"] = out["final_conv.weight"] * float(logit_gain)
+        out["final_conv.bias"] = out["final_conv.bias"] * float(logit_gain)
+    return out
+
+
 def state_fingerprint(sd):
     """Cheap cross-machine identity check of a generated state dict."""
     acc = 0.0
@@ -222,13 +252,20 @@ def state_fingerprint(sd):
     return acc
 
 
-def synthetic_clip(t, h, w, k, seed=0):
+def synthetic_clip(t, h, w, k, seed=0, texture=0.0):
     """Band-limited random RGB frames (ImageNet-normalised as dataset/range_transform.py:5-8)
     and K disjoint moving ellipses.  Returns images [1,T,3,h,w] f32, masks one-hot
-    [T,K+1,1,h,w] f32 (channel 0 = background)."""
+    [T,K+1,1,h,w] f32 (channel 0 = background).  `texture` > 0 adds a fine-grained (2-pixel) random pattern of that
+    amplitude (in units of the coarse pattern's) that morphs over the clip like the coarse one: stride-16 keys of
+    neighbouring positions then differ the way they do on real footage (closed-loop parity fixtures; 0 = the
+    band-limited clip every golden vector was made with, bit for bit)."""
     r = np.random.RandomState(1234 + seed)
     base = r.standard_normal((3, h // 8 + 2, w // 8 + 2)).astype(np.float32)
     drift = r.standard_normal((3, h // 8 + 2, w // 8 + 2)).astype(np.float32)
+    if texture:
+        rt = np.random.RandomState(4321 + seed)
+        fine = [torch.from_numpy(rt.standard_normal((3, h // 2 + 2, w // 2 + 2)).astype(np.float32))[None] for _ in range(2)]
+        fine = [F.interpolate(f, size=(h, w), mode="bicubic", align_corners=False)[0].numpy() for f in fine]
     mean = np.array([0.485, 0.456, 0.406], np.float32)[:, None, None]
     std = np.array([0.229, 0.224, 0.225], np.float32)[:, None, None]
     frames = []
@@ -236,6 +273,8 @@ def synthetic_clip(t, h, w, k, seed=0):
         a = i / max(t - 1, 1)
         lo = torch.from_numpy((1 - a) * base + a * drift)[None]
         img = F.interpolate(lo, size=(h, w), mode="bicubic", align_corners=False)[0].numpy()
+        if texture:
+            img = img + np.float32(texture) * (np.float32(1 - a) * fine[0] + np.float32(a) * fine[1])
         img = np.clip(0.5 + 0.22 * img, 0, 1)
         img = np.round(img * 255) / 255
         frames.append((img - mean) / std)

@@ -22,6 +22,13 @@ STUB = textwrap.dedent("""
             s = self.spec
             out = np.stack([np.roll(mask, t, axis=1) for t in range(s.frames)], 0).astype(np.uint8)
             return out
+        def interact_steps(self, mask, idx):
+            for t in range(self.spec.frames - 1):
+                TRACE.append((self.spec.clip_id, t))
+                yield t
+            return self.interact(mask, idx)
+
+    TRACE = []
 
     def factory(spec):
         r = np.random.RandomState(spec.seed)
@@ -55,6 +62,36 @@ def test_single_process_suite_and_summary():
         raise AssertionError("duplicate clip not detected")
     except RuntimeError:
         pass
+
+
+def test_two_lanes_interleave_clips_and_reproduce_the_sequential_suite():
+    """run_suite(lanes=2): two clips in flight, advanced in turn one frame at a time, every lane inside its own context; the records
+    (checksums, frames) equal the one-clip-at-a-time run, each clip is processed once, and the clips' seconds add up to the wall clock."""
+    import contextlib
+    ns = {}
+    exec(STUB, ns)
+    specs = ES.synthetic_suite(7)
+    ref = ES.run_suite(specs, ns["factory"])
+    entered = []
+
+    @contextlib.contextmanager
+    def lane_ctx(lane):
+        entered.append(lane)
+        yield
+
+    seen = []
+    recs = ES.run_suite(specs, ns["factory"], lanes=2, lane_ctx=lane_ctx, on_clip=lambda s, m: seen.append(s.clip_id))
+    assert sorted(seen) == list(range(7)) and set(entered) == {0, 1}
+    assert [(r["clip"], r["frames"], r["checksum"]) for r in recs] == [(r["clip"], r["frames"], r["checksum"]) for r in ref]
+    assert ES.summarize(recs, 7)["checksum"] == ES.summarize(ref, 7)["checksum"]
+    trace = ns["TRACE"]
+    # two different clips alternate frame by frame while both are in flight
+    switches = sum(1 for a, b in zip(trace, trace[1:]) if a[0] != b[0])
+    assert switches > len(trace) // 2, (switches, len(trace))
+    for cid in range(7):                                  # and every clip's frames come in order
+        ts = [t for c, t in trace if c == cid]
+        assert ts == list(range(specs[cid].frames - 1))
+    assert all(r["seconds"] > 0 and r["lanes"] == 2 for r in recs)
 
 
 def test_two_rank_gloo_suite(tmp_path):

@@ -471,6 +471,36 @@ def test_mem_profiles_give_identical_results(nets):
     assert ref.shape == (6, 100, 141) and ref_core.pad == (1, 2, 6, 6) and ref_core.prob.shape == (3, 6, 1, 112, 144)
 
 
+def test_concurrent_passes_and_suite_lanes_are_bit_identical(nets):
+    """Two independent propagation chains advanced in turn on two HIP streams - the forward / backward pass of a mid-clip interaction
+    (InferenceCore._run_passes) and two clips of a suite (eval_suite.run_suite(lanes=2)) - must give the bits of the one-after-the-other
+    order: same kernels on the same inputs; anything else is a race (shared scratch, a missing stream dependency)."""
+    from mivos_amd import eval_suite as ES
+    from mivos_amd.util import synthetic
+    prop, fuse = nets
+    images, gt = O.synthetic_clip(11, 240, 432, 3, seed=46)
+    runs = {}
+    for conc in (False, True):
+        core = InferenceCore(prop, fuse, images, 3, mem_freq=2, device=DEV)
+        core.CONCURRENT_PASSES = conc
+        outs = [core.interact(gt[idx], idx).copy() for idx in (0, 10, 5, 7)]        # 5 and 7: both passes exist, both fused
+        runs[conc] = (outs, core.prob.clone(), core.propagated_frames)
+        assert (core._pass_stream is not None) == conc
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert np.array_equal(a, b)
+    assert torch.equal(runs[False][1], runs[True][1]) and runs[False][2] == runs[True][2]
+
+    specs = [ES.ClipSpec(0, 9, 3, 240, 432, 11), ES.ClipSpec(1, 14, 1, 240, 432, 12), ES.ClipSpec(2, 6, 5, 240, 432, 13), ES.ClipSpec(3, 12, 2, 240, 432, 14)]
+
+    def factory(spec):
+        im, g = synthetic.synthetic_clip_device(spec.frames, spec.height, spec.width, spec.objects, seed=spec.seed, device=DEV)
+        return InferenceCore(prop, fuse, im, spec.objects, mem_freq=3, device=DEV), g[0]
+    one = ES.run_suite(specs, factory, sync=torch.cuda.synchronize)
+    two = ES.run_suite(specs, factory, sync=torch.cuda.synchronize, lanes=2, lane_ctx=ES.stream_lanes(DEV, 2))
+    assert [(r["clip"], r["checksum"]) for r in one] == [(r["clip"], r["checksum"]) for r in two]
+    assert all(r["lanes"] == 2 for r in two)
+
+
 def test_interaction_order_and_reinteraction_vs_oracle(nets, synthetic_states):
     """Last frame first, then the first frame (pure backward + fused pass), then the SAME frame again
     (certain memory grows by a duplicate, exactly like the reference's torch.cat at :243-245)."""
