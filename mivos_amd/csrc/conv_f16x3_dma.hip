@@ -48,7 +48,7 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 constexpr int ROWB = 128;   // bytes per tile row and K step: 32 k x (hi, lo) fp16
 constexpr unsigned OOB_OFFSET = 0x80000000u;   // + any step offset stays >= num_records (< 2 GB) without wrapping
 
-template <int BM, int BN, int WGM, int WGN, int ABL = 0>   // ABL: profiling ablations (1: no DMA, 2: no DMA wait, 3: no fragment reads)
+template <int BM, int BN, int WGM, int WGN, int ABL = 0>   // ABL: profiling ablations (1: no DMA, 2: no DMA wait, 3: no fragment reads); 9: experimental merged-half-step schedule
 __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_bytes, unsigned w_bytes) {
   static_assert(WGM * WGN == 8, "8 waves per workgroup");
   static_assert(BM % 64 == 0 && BN % 64 == 0, "tile rows are fetched 64 at a time");
@@ -141,34 +141,37 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
     }
 
   h8 ah[MT], al[MT], bh[NT], bl[NT];
-  auto load_frags = [&](int sa, int sb, int kk) {
+  h8 ah1[MT], al1[MT], bh1[NT], bl1[NT];          // second fragment set: the merged-half-step schedule only (ABL == 9; dead code otherwise)
+  auto load_frags_into = [&](h8 (&AH)[MT], h8 (&AL)[MT], h8 (&BH)[NT], h8 (&BL)[NT], int sa, int sb, int kk) {
     if (ABL == 3) return;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      bh[j] = *reinterpret_cast<const h8 *>(fb[0][kk] + sb * B_STAGE + j * 32 * ROWB);
-      bl[j] = *reinterpret_cast<const h8 *>(fb[1][kk] + sb * B_STAGE + j * 32 * ROWB);
+      BH[j] = *reinterpret_cast<const h8 *>(fb[0][kk] + sb * B_STAGE + j * 32 * ROWB);
+      BL[j] = *reinterpret_cast<const h8 *>(fb[1][kk] + sb * B_STAGE + j * 32 * ROWB);
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      ah[i] = *reinterpret_cast<const h8 *>(fa[0][kk] + sa * A_STAGE + i * 32 * ROWB);
-      al[i] = *reinterpret_cast<const h8 *>(fa[1][kk] + sa * A_STAGE + i * 32 * ROWB);
+      AH[i] = *reinterpret_cast<const h8 *>(fa[0][kk] + sa * A_STAGE + i * 32 * ROWB);
+      AL[i] = *reinterpret_cast<const h8 *>(fa[1][kk] + sa * A_STAGE + i * 32 * ROWB);
     }
   };
+  auto load_frags = [&](int sa, int sb, int kk) { load_frags_into(ah, al, bh, bl, sa, sb, kk); };
   // per accumulator the three products keep the order of conv_f16x3.hip (lo*hi, hi*lo, hi*hi): bit-identical sums
-  auto mfma_phase = [&]() {
+  auto mfma_phase_on = [&](const h8 (&AH)[MT], const h8 (&AL)[MT], const h8 (&BH)[NT], const h8 (&BL)[NT]) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[j], acc[i][j], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[j], acc[i][j], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BH[j], acc[i][j], 0, 0, 0);
   };
+  auto mfma_phase = [&]() { mfma_phase_on(ah, al, bh, bl); };
   auto phase_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -181,6 +184,39 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
     constexpr int U = decltype(u_tag)::value;
     constexpr bool TAIL = decltype(tail_tag)::value;
     constexpr int sa = U % 3, sb = U % 2;
+    if constexpr (ABL == 9) {
+      // EXPERIMENTAL (MIVOS_PP_MERGE=1, off by default; design note in docs/NOTEBOOK.md): ONE load phase and ONE MFMA phase per K step - two
+      // barriers instead of four.  The DMA burst k = {weights of step k + 1, activations of step k + 2} is issued by BOTH wave groups in the
+      // same wall-clock phase - group 0 from LOAD(k), group 1 (one phase behind) from the start of MFMA(k - 1) - and both wait for it at the
+      // end of their next phase (vmcnt(A_LD): everything but the newest activation pieces), so that every wave's rows of step k + 1 have
+      // landed one barrier before anybody reads them.  The stages a burst overwrites were last read two phases earlier by either group.
+      // Same MFMA order per accumulator as the two half steps: bit-identical results.
+      const bool g1 = wave >= 4;
+      load_frags_into(ah, al, bh, bl, sa, sb, 0);
+      load_frags_into(ah1, al1, bh1, bl1, sa, sb, 1);
+      if (!g1) {
+        if (!TAIL || kt + 1 < nk) issue_b(sb ^ 1);
+        if (!TAIL || kt + 2 < nk) issue_a((sa + 2) % 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else if (TAIL) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(A_LD) : "memory");
+      }
+      phase_barrier();
+      if (g1) {                                                // burst kt + 1: weights of step kt + 2 over THIS step's weight stage, activations
+        if (!TAIL || kt + 2 < nk) issue_b(sb);                 // of step kt + 3 over this step's activation stage (both just read)
+        if (!TAIL || kt + 3 < nk) issue_a(sa);
+      }
+      mfma_phase_on(ah, al, bh, bl);
+      mfma_phase_on(ah1, al1, bh1, bl1);
+      if (!g1) {
+        if (TAIL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD) : "memory");
+      }
+      phase_barrier();
+      return;
+    }
     load_frags(sa, sb, 0);                                     // L(kt, 0)
     if (ABL != 1 && (!TAIL || kt + 1 < nk)) issue_b(sb ^ 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -212,9 +248,13 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
   if (nk > 1) issue_a(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   phase_barrier();                       // step 0 (and the activations of step 1) landed for everybody
+  if (ABL == 9 && wave >= 4) {           // merged schedule: group 1 issues burst 0 in the phase in which group 0 runs LOAD(0)
+    if (1 < nk) issue_b(1);
+    if (2 < nk) issue_a(2);
+  }
   if (wave >= 4) phase_barrier();        // G1 runs one phase behind
   int kt = 0;
-  for (; kt + 8 <= nk; kt += 6) {        // every step of the group still has its two prefetches
+  for (; kt + (ABL == 9 ? 9 : 8) <= nk; kt += 6) {        // every step of the group still has its prefetches (merged: group 1 looks 3 steps ahead)
     step(kt, integral_constant<int, 0>{}, steady{});
     step(kt + 1, integral_constant<int, 1>{}, steady{});
     step(kt + 2, integral_constant<int, 2>{}, steady{});
@@ -406,7 +446,12 @@ int launch_conv_f16x3_dma(ConvP &p, hipStream_t st) {
       return launch_pp<128, 256, 2, 4>(p, st);
     }
     case 22: return launch_pp<128, 64, 4, 2>(p, st);
-    default: return launch_pp<128, 128, 2, 4>(p, st);
+    case 24: return launch_pp<64, 128, 2, 4>(p, st);       // 64-row tiles: M = 8100 layers as 127 row tiles (56 KB LDS: two workgroups per CU)
+    default: {
+      static const int merge = getenv("MIVOS_PP_MERGE") ? atoi(getenv("MIVOS_PP_MERGE")) : 0;   // experimental schedule (round-5 experiment), off
+      if (merge) return launch_pp<128, 128, 2, 4, 9>(p, st);
+      return launch_pp<128, 128, 2, 4>(p, st);
+    }
   }
 }
 

@@ -252,6 +252,7 @@ import collections
 
 _act_scratch = collections.OrderedDict()
 ACT_SCRATCH_ENTRIES = 256   # scratch buffers kept per process (least recently used ones go first)
+COUT1_PROJECTION = True # one-output-channel 3x3 layers as a 1x1 projection to nine tap products + tap_sum9 (False: the generic kernels; diagnostics)
 USE_ACT_PATH = True     # run conv -> conv edges on the LDS-DMA kernels (needs CONV_PRECISION == "f16x3")
 
 
@@ -329,7 +330,7 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
         raise MivosHipError("conv: an Act input needs the f16x3 back-end, Cout > 1 and relu applied by its producer")
     if out_act and not from_act:
         raise MivosHipError("conv: SH32 outputs are written by the LDS-DMA kernels only (Act input)")
-    if (L.cout == 1 and L.k == 3 and L.stride == 1 and L.pad == 1 and L.dil == 1 and L.scale is None and CONV_PRECISION == "f16x3"
+    if (L.cout == 1 and L.k == 3 and L.stride == 1 and L.pad == 1 and L.dil == 1 and L.scale is None and CONV_PRECISION == "f16x3" and COUT1_PROJECTION
             and not from_act and res is None and not relu_out and cin % 32 == 0):
         # one output channel: 1x1 projection to the nine tap products (reads x once) + 9-point sum, instead of a dot-product
         # kernel that re-reads every pixel for each of its nine neighbours

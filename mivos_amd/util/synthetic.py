@@ -213,10 +213,12 @@ def make_s2m_state(seed=0, calib="golden"):
     return sd
 
 
-def condition_state(sd, key_gain=1.0, logit_gain=1.0, mask_gain=1.0):
+def condition_state(sd, key_gain=1.0, logit_gain=1.0, mask_gain=1.0, logit_bias=0.0, resid_gain=1.0):
     """Post-hoc gains on a PropagationNetwork state dict (returns a new dict; `sd` is not modified): `key_gain` scales both
     key projections (affinity x key_gain^2: sharper top-k softmax), `logit_gain` the decoder's last layer (mask logits),
-    `mask_gain` the stem weights of the mask / "others" input channels of the memory encoder (feedback gain).  Used by the
+    `mask_gain` the stem weights of the mask / "others" input channels of the memory encoder (feedback gain), `logit_bias` is
+    added to the mask logit after the gain (negative: the background wins wherever no object-specific evidence exists - without
+    it the untrained decoder hands every pixel to SOME object and the K objects tie exactly where their inputs coincide).  Used by the
     closed-loop parity fixtures (scripts/studies/fixture_conditioning.py, scripts/long_session_parity.py); gains of 1 return
     the golden weights bit for bit."""
     out = OrderedDict((k, v.clone()) for k, v in sd.items())
@@ -227,6 +229,16 @@ def condition_state(sd, key_gain=1.0, logit_gain=1.0, mask_gain=1.0):
     if logit_gain != 1.0:
         out["decoder.pred.weight"] = out["decoder.pred.weight"] * float(logit_gain)
         out["decoder.pred.bias"] = out["decoder.pred.bias"] * float(logit_gain)
+    if logit_bias != 0.0:
+        out["decoder.pred.bias"] = out["decoder.pred.bias"] + float(logit_bias)
+    if resid_gain != 1.0:
+        # residual branches of the memory encoder's bottlenecks (their last BatchNorm's affine) and of the decoder's ResBlocks (conv2):
+        # the closer to 0, the closer the untrained network is to a smooth, monotone function of its mask input
+        for k in list(out):
+            if k.startswith("mask_rgb_encoder.") and (k.endswith(".bn3.weight") or k.endswith(".bn3.bias")):
+                out[k] = out[k] * float(resid_gain)
+            if k.startswith("decoder.") and (k.endswith(".conv2.weight") or k.endswith(".conv2.bias")) and "skip_conv2" not in k:
+                out[k] = out[k] * float(resid_gain)
     if mask_gain != 1.0:
         w = out["mask_rgb_encoder.conv1.weight"].clone()
         w[:, 3:] *= float(mask_gain)

@@ -340,7 +340,7 @@ class OracleCore:
         self.trace.append("M")
         return memorize(self.sd, self.images[:, ti], masks)
 
-    def do_pass(self, key_k, idx, forward=True):                               # :122-200
+    def do_pass(self, key_k, idx, forward=True, step_cb=None):                 # :122-200
         nc = self.certain_k.shape[2]
         m_front = nc
         if forward:
@@ -395,6 +395,8 @@ class OracleCore:
             if rec is not None:
                 self.step_hook(rec)
             self.propagated += 1
+            if step_cb is not None:                                                # :195-196
+                step_cb()
         return closest
 
     def fuse_one_frame(self, tc, tr, ti, prev, curr, mk16, qk16):              # :202-217
@@ -413,7 +415,7 @@ class OracleCore:
         self.last_fuse_logits, self.last_fuse_attn = torch.cat(logits, 0), torch.cat(attns, 0)      # [K,1,nh,nw], [K,2,nh,nw]
         return aggregate_wbg(prob, keep_bg=True)
 
-    def interact(self, mask, idx):                                             # :219-271
+    def interact(self, mask, idx, total_cb=None, step_cb=None):                # :219-271
         self.interacted.add(idx)
         mask, _ = pad_divide_by(mask.to(self.dtype), 16)
         diff = mask - self.prob[:, idx]
@@ -425,8 +427,13 @@ class OracleCore:
         else:
             self.certain_k = torch.cat([self.certain_k, key_k], 2)
             self.certain_v = torch.cat([self.certain_v, key_v], 2)
-        self.do_pass(key_k, idx, True)
-        self.do_pass(key_k, idx, False)
+        if total_cb is not None:                                                   # :247-253
+            front = min([ti for ti in self.interacted if ti > idx] + [self.t])
+            back = max([ti for ti in self.interacted if ti < idx] + [-1])
+            if front - back - 2 > 0:
+                total_cb(front - back - 2)
+        self.do_pass(key_k, idx, True, step_cb)
+        self.do_pass(key_k, idx, False, step_cb)
         for ti in range(self.t):
             self.masks[ti] = torch.argmax(self.prob[:, ti], dim=0)
         lw, uw, lh, uh = self.pad

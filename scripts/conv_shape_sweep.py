@@ -19,7 +19,7 @@ SHAPES = [  # name, N, H, W, Cin, Cout, k, stride, residual
     ("l2 3x3 128->128", 5, 60, 108, 128, 128, 3, 1, False), ("l2 1x1 128->512 +res", 5, 60, 108, 128, 512, 1, 1, True),
     ("l1 1x1 64->256 +res", 5, 120, 216, 64, 256, 1, 1, True), ("l1 1x1 256->128", 5, 120, 216, 256, 128, 1, 1, False),
 ]
-COMBOS = [(0, 0)] + [(t, s) for t in (20, 21, 22) for s in (1, 2, 4)]      # (MIVOS_PP_TILE, MIVOS_PP_SPLIT); (0, 0) = the library's own choice
+COMBOS = [(0, 0)] + [(t, s) for t in (20, 26, 21, 22, 24) for s in (1, 2, 4)]      # (MIVOS_PP_TILE, MIVOS_PP_SPLIT); (0, 0) = the library's own choice; 26 = tile 20 with MIVOS_PP_MERGE=1
 
 
 def child():
@@ -56,10 +56,15 @@ def main():
     for tile, split in COMBOS:
         env = dict(os.environ)
         if tile:
-            env["MIVOS_PP_TILE"], env["MIVOS_PP_SPLIT"] = str(tile), str(split)
+            env["MIVOS_PP_TILE"], env["MIVOS_PP_SPLIT"] = str(20 if tile == 26 else tile), str(split)
+            if tile == 26:
+                env["MIVOS_PP_MERGE"] = "1"
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         table[(tile, split)] = json.loads(line[-1]) if line else {}
+    if "--json" in sys.argv:
+        with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
+            json.dump({f"{t}/{s}": v for (t, s), v in table.items()}, f)
     print("shape | default | " + " | ".join(f"t{t}/s{s}" for t, s in COMBOS[1:]))
     for name, *_ in SHAPES:
         print(f"{name:24s} {table[(0, 0)].get(name, '-'):>8} | " + " | ".join(f"{table[c].get(name, '-'):>7}" for c in COMBOS[1:]))

@@ -28,12 +28,22 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-CFG = dict(frames=70, height=480, width=854, objects=5, top_k=50, mem_freq=5, seed=100, interactions=[0, 69])
+CFG = dict(frames=70, height=480, width=854, objects=5, top_k=50, mem_freq=5, seed=100, interactions=[0, 69],
+           # conditioning of the fixture (synthetic.condition_state / synthetic_clip(texture=...)); all 1 / 0 = the round-4 fixture
+           key_gain=1.0, logit_gain=1.0, mask_gain=1.0, logit_bias=0.0, fuse_logit_gain=1.0, texture=0.0, clip_frames=None)
 
 
 def clip(cfg):
+    """The clip: `frames` frames; with clip_frames = N > frames the first `frames` of an N-frame clip (the per-step motion of the long clip)."""
     from mivos_amd.util import synthetic
-    return synthetic.synthetic_clip(cfg["frames"], cfg["height"], cfg["width"], cfg["objects"], seed=cfg["seed"])
+    images, gt = synthetic.synthetic_clip(cfg["clip_frames"] or cfg["frames"], cfg["height"], cfg["width"], cfg["objects"], seed=cfg["seed"], texture=cfg["texture"])
+    return images[:, :cfg["frames"]], gt[:cfg["frames"]]
+
+
+def states(cfg):
+    from mivos_amd.util import synthetic
+    return (synthetic.condition_state(synthetic.make_prop_state(0), key_gain=cfg["key_gain"], logit_gain=cfg["logit_gain"], mask_gain=cfg["mask_gain"], logit_bias=cfg["logit_bias"]),
+            synthetic.condition_fuse_state(synthetic.make_fuse_state(0), logit_gain=cfg["fuse_logit_gain"]))
 
 
 def run_oracle(args, cfg):
@@ -43,8 +53,8 @@ def run_oracle(args, cfg):
     os.makedirs(args.out, exist_ok=True)
     dt = torch.float64 if args.dtype == "fp64" else torch.float32
     images, gt = clip(cfg)
-    core = O.OracleCore(synthetic.make_prop_state(0), synthetic.make_fuse_state(0), images, cfg["objects"], mem_freq=cfg["mem_freq"],
-                        top_k=cfg["top_k"], dtype=dt, record_margins=True)
+    sd, fsd = states(cfg)
+    core = O.OracleCore(sd, fsd, images, cfg["objects"], mem_freq=cfg["mem_freq"], top_k=cfg["top_k"], dtype=dt, record_margins=True)
     t0 = time.perf_counter()
     for n, idx in enumerate(cfg["interactions"]):
         masks = core.interact(gt[idx], idx)
@@ -95,6 +105,14 @@ def run_engine(args, cfg):
     dev = "cuda:0"
     from mivos_amd import ops
     ops.CONV_PRECISION = args.precision
+    ops.AFFINITY_PRECISION = args.affinity
+    if args.no_act_path:
+        ops.USE_ACT_PATH = False
+    if args.no_stem_kernel:
+        from mivos_amd.model.propagation import modules
+        modules.STEM_FROM_PLANES = False
+    if args.no_cout1_projection:
+        ops.COUT1_PROJECTION = False
     t_wait = time.time()
     for d in (args.ref32, args.ref64):
         while d and not os.path.exists(os.path.join(d, "done")):
@@ -107,12 +125,13 @@ def run_engine(args, cfg):
             time.sleep(5)
     K = cfg["objects"]
     prop, fuse = PropagationNetwork(top_k=cfg["top_k"]), FusionNet()
-    prop.load_state_dict(synthetic.make_prop_state(0))
-    fuse.load_state_dict(synthetic.make_fuse_state(0))
+    sd, fsd = states(cfg)
+    prop.load_state_dict(sd)
+    fuse.load_state_dict(fsd)
     prop, fuse = prop.to(dev).eval(), fuse.to(dev).eval()
     images, gt = clip(cfg)
     core = InferenceCore(prop, fuse, images, K, mem_freq=cfg["mem_freq"], device=dev)
-    out = dict(config=cfg, engine_precision=args.precision, oracle_fp32=json.load(open(os.path.join(args.ref32, "done"))),
+    out = dict(config=cfg, engine_precision=args.precision, affinity_precision=ops.affinity_precision(), act_path=ops.act_path(), toggles=dict(no_stem_kernel=args.no_stem_kernel, no_cout1_projection=args.no_cout1_projection), oracle_fp32=json.load(open(os.path.join(args.ref32, "done"))),
                oracle_fp64=json.load(open(os.path.join(args.ref64, "done"))) if args.ref64 else None, interactions=[])
     for n, idx in enumerate(cfg["interactions"]):
         t0 = time.perf_counter()
@@ -150,7 +169,12 @@ def run_engine(args, cfg):
         if p64 is not None:
             summ.update(min_iou_engine_vs_fp64=min(f["iou_engine_vs_fp64"] for f in live), min_iou_ref32_vs_fp64=min(f["iou_ref32_vs_fp64"] for f in live),
                         max_engine_vs_fp64=max(f["engine_vs_fp64_max"] for f in live), max_ref32_vs_fp64=max(f["ref32_vs_fp64_max"] for f in live),
-                        worst_q999_engine_vs_fp64=max(f["engine_vs_fp64_q999"] for f in live), worst_q999_ref32_vs_fp64=max(f["ref32_vs_fp64_q999"] for f in live))
+                        worst_q999_engine_vs_fp64=max(f["engine_vs_fp64_q999"] for f in live), worst_q999_ref32_vs_fp64=max(f["ref32_vs_fp64_q999"] for f in live),
+                        # e / r per frame: how far the engine is from the fp64 run relative to how far the reference's own fp32 run is
+                        median_ratio_of_maxima=round(float(np.median([f["engine_vs_fp64_max"] / max(f["ref32_vs_fp64_max"], 1e-12) for f in live])), 3),
+                        median_ratio_of_q999=round(float(np.median([f["engine_vs_fp64_q999"] / max(f["ref32_vs_fp64_q999"], 1e-12) for f in live])), 3),
+                        worst_ratio_of_maxima=round(float(max(f["engine_vs_fp64_max"] / max(f["ref32_vs_fp64_max"], 1e-12) for f in live)), 3),
+                        frames_ref32_vs_fp64_below_09995=[f["frame"] for f in live if f["iou_ref32_vs_fp64"] < 0.9995])
         print(json.dumps(summ), flush=True)
         out["interactions"].append(dict(summary=summ, frames=frames))
     os.makedirs(os.path.dirname(os.path.abspath(args.json)), exist_ok=True)
@@ -171,13 +195,20 @@ def main():
     ap.add_argument("--json", default=os.path.join(ROOT, "gpurun_out", "long_session_parity.json"))
     ap.add_argument("--precision", default="f16x3", choices=("f16x3", "f32"),
                     help="engine phase: ops.CONV_PRECISION - f16x3 (the default engine) or f32 (every convolution and the affinity on exact fp32 MFMA)")
+    ap.add_argument("--affinity", default=None, choices=("f16x3", "f32"), help="engine phase: pin the memory-read affinity's arithmetic (default: follows --precision)")
+    ap.add_argument("--no-act-path", action="store_true", help="engine phase (diagnostics): every convolution on the register-staged f16x3 kernels from fp32 activations (no SH32 tensors)")
+    ap.add_argument("--no-stem-kernel", action="store_true", help="engine phase (diagnostics): the 7x7 stems on the generic convolution kernels")
+    ap.add_argument("--no-cout1-projection", action="store_true", help="engine phase (diagnostics): decoder.pred on the generic kernels instead of projection + tap sum")
+    for k in ("key_gain", "logit_gain", "mask_gain", "logit_bias", "fuse_logit_gain", "texture"):
+        ap.add_argument("--" + k.replace("_", "-"), type=float, default=None)
+    ap.add_argument("--clip-frames", type=int, default=None)
     ap.add_argument("--frames", type=int, default=None, help="shorter clip (smoke runs)")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--objects", type=int, default=None)
     args = ap.parse_args()
     cfg = dict(CFG)
-    for k in ("frames", "height", "width", "objects"):
+    for k in ("frames", "height", "width", "objects", "key_gain", "logit_gain", "mask_gain", "logit_bias", "fuse_logit_gain", "texture", "clip_frames"):
         if getattr(args, k) is not None:
             cfg[k] = getattr(args, k)
     cfg["interactions"] = [0, cfg["frames"] - 1]

@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--key-gain", type=float, default=1.0)
     ap.add_argument("--logit-gain", type=float, default=1.0)
     ap.add_argument("--mask-gain", type=float, default=1.0)
+    ap.add_argument("--logit-bias", type=float, default=0.0)
+    ap.add_argument("--resid-gain", type=float, default=1.0)
     ap.add_argument("--fuse-logit-gain", type=float, default=1.0)
     ap.add_argument("--texture", type=float, default=0.0, help="amplitude of per-pixel texture added to the clip (0 = the band-limited clip)")
     ap.add_argument("--second", type=int, default=-1, help="second interaction frame (default: last; -2: none)")
@@ -50,7 +52,7 @@ def main():
     from mivos_amd.util.tensor_util import compute_np_iou
     images, gt = synthetic.synthetic_clip(args.clip_frames or args.frames, args.height, args.width, args.objects, seed=args.seed, texture=args.texture)
     images, gt = images[:, :args.frames], gt[:args.frames]
-    sd = synthetic.condition_state(synthetic.make_prop_state(0), key_gain=args.key_gain, logit_gain=args.logit_gain, mask_gain=args.mask_gain)
+    sd = synthetic.condition_state(synthetic.make_prop_state(0), key_gain=args.key_gain, logit_gain=args.logit_gain, mask_gain=args.mask_gain, logit_bias=args.logit_bias, resid_gain=args.resid_gain)
     fsd = synthetic.condition_fuse_state(synthetic.make_fuse_state(0), logit_gain=args.fuse_logit_gain)
     inter = [0] + ([] if args.second == -2 else [args.frames - 1 if args.second == -1 else args.second])
     runs = {}

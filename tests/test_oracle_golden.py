@@ -214,3 +214,32 @@ def test_update_mask_only_golden(golden_dir, synthetic_states):
         out = core.update_mask_only(pm, idx)
         assert out.dtype == np.uint8 and np.array_equal(out, g[f"np_masks_{n}"])
         assert np.array_equal(core.masks[idx].numpy(), g[f"masks_idx_{n}"])
+
+
+def test_gui_call_pattern_golden(golden_dir, synthetic_states):
+    """The GUI's way of driving the processor (interactive_gui.py:550, 616, 626, 636-642, 889-897, 955-960; oracle/gui_replay.py) replayed
+    on the oracle: `current_mask` after every handler, the progress-bar calls, the final buffers and what local mode reads equal what the
+    UNMODIFIED reference InferenceCore produced (tests/golden/gui_small.npz, oracle/make_golden_gui.py)."""
+    from oracle import gui_replay as G
+    from oracle.make_golden_gui import pack
+    sd, fsd = synthetic_states
+    with np.load(os.path.join(golden_dir, "gui_small.npz")) as z:
+        gold = {k: z[k] for k in z.files}
+    cfg = json.loads(str(gold["config"]))
+    assert cfg == G.SESSION
+    images, gt = O.synthetic_clip(cfg["t"], cfg["h"], cfg["w"], cfg["k"], cfg["seed"])
+    core = O.OracleCore(sd, fsd, images, cfg["k"], mem_freq=cfg["mem_freq"], top_k=cfg["top_k"])
+    g, local = G.scripted_session(core, gt)
+    out = pack(g, local, core)
+    assert [n for n, _ in g.events] == [str(n) for n in gold["event_names"]]
+    assert out["progress"].tolist() == gold["progress"].tolist() == [6] + [-1] * 6 + [5] + [-1] * 5 + [4] + [-1] * 4 + [1, -1]
+    for k in gold:
+        if k in ("config", "event_names", "final_prob", "local_prev_soft_mask"):
+            continue
+        assert np.array_equal(out[k], gold[k]), k
+    assert np.abs(out["final_prob"] - gold["final_prob"]).max() <= TOL
+    assert np.abs(out["local_prev_soft_mask"] - gold["local_prev_soft_mask"]).max() <= TOL
+    # the in-place reset of frame 2 reached the processor's own buffers and the next interaction rebuilt them
+    names = [n for n, _ in g.events]
+    reset = g.events[names.index("reset")][1]
+    assert not reset[2].any() and reset[3].any()
