@@ -45,6 +45,9 @@ VARIANT_NAMES = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<64,6
                  20: "conv_f16x3_pp_kernel<128,128,2,4,0>", 21: "conv_f16x3_pp_kernel<128,256,2,4,0>",
                  22: "conv_f16x3_pp_kernel<128,64,4,2,0>", 23: "conv_f16x3_pp_kernel<256,256,2,4,0>",
                  30: "fusion_net_forward (conv1 + 2 x fusion_resblock_kernel + fusion_head_kernel)", 90: "memread_select_kernel", 91: "memread_finalize_kernel"}
+# clips in flight per GPU (see --lanes): a 480p frame of 1-5 objects leaves most of the 256 CUs idle at the 1/16-resolution layers, a second
+# clip on a second stream fills them (profiles/r05a_suite_lanes_ab.txt: config 4 199.7 -> 233.3 -> 241.4 frames/s at 1 / 2 / 3 lanes, identical masks)
+DEFAULT_LANES = int(os.environ.get("MIVOS_BENCH_LANES", "1"))
 CONFIGS = {
     2: dict(name="davis480p_single_object", height=480, width=854, frames=70, objects=1, top_k=20, interactions=(0,)),
     3: dict(name="davis480p_multiobject_fusion", height=480, width=854, frames=70, objects=5, top_k=50, interactions=(0, -1)),
@@ -58,7 +61,7 @@ class StepClock:
 
     def __init__(self, warmup, steps, profile_every, ops, shard, torch):
         self.warmup, self.steps, self.every, self.ops, self.shard, self.torch = warmup, steps, profile_every, ops, shard, torch
-        self.n, self.t0, self.t1, self.samples, self.core, self.dropped = 0, None, None, [], None, 0
+        self.n, self.t0, self.t1, self.samples, self.cores, self.dropped = 0, None, None, [], [], 0
 
     def _stamp(self):
         self.torch.cuda.synchronize()
@@ -68,8 +71,7 @@ class StepClock:
 
     def arm(self):
         if self.n == self.warmup and self.t0 is None:
-            if self.core is not None:
-                self.dropped = self.core.drop_lookahead()
+            self.dropped = sum(c.drop_lookahead() for c in self.cores if c is not None)
             self.t0 = self._stamp()
         timed = self.t0 is not None and self.t1 is None
         # sample every `every`-th timed step with HIP events around each conv / memory-read launch
@@ -266,50 +268,101 @@ def cpu_baseline(torch, cfg, images, gt, mem_freq, prop, fuse, dev, n_frames, wi
                 seconds=round(dt, 2), host_cores=os.cpu_count()), parity
 
 
-def run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, mem_freq, warmup, steps, profile_every):
+def run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, mem_freq, warmup, steps, profile_every, lanes=1):
     """Repeat the configuration's session (fresh InferenceCore over the HBM-resident clip) until `warmup + steps` steps
-    have run.  Returns (clock, masks of the first session's first interaction)."""
+    have run.  Returns (clock, masks of the first session's first interaction).
+
+    lanes > 1: that many sessions are in flight on this GPU, each on its own HIP stream, advanced in turn one propagated frame at a
+    time (InferenceCore.interact_steps) - what eval_suite.run_suite(lanes=...) does with the clips of a suite.  A step is still one
+    propagated frame (of whichever session); the timed region still holds exactly `steps` of them."""
     from mivos_amd.inference_core import InferenceCore
     clock = StepClock(warmup, steps, profile_every, ops, shard, torch)
     T = images.shape[1]
     first = None
-    while not clock.done:
-        core = InferenceCore(prop, fuse, images, cfg["objects"], mem_profile=0, mem_freq=mem_freq, device=dev)
-        clock.core = core
-        clock.arm()
-        for i in cfg["interactions"]:
-            idx = i % T
-            out = core.interact(gt[idx], idx, step_cb=clock)
-            if first is None:
-                first = out.copy()
-        del core
+    if lanes <= 1:
+        while not clock.done:
+            core = InferenceCore(prop, fuse, images, cfg["objects"], mem_profile=0, mem_freq=mem_freq, device=dev)
+            clock.cores = [core]
+            clock.arm()
+            for i in cfg["interactions"]:
+                idx = i % T
+                out = core.interact(gt[idx], idx, step_cb=clock)
+                if first is None:
+                    first = out.copy()
+            del core
+    else:
+        clock.cores = [None] * lanes
+        firsts = [None] * lanes
+
+        def session_loop(lane):
+            while not clock.done:
+                core = InferenceCore(prop, fuse, images, cfg["objects"], mem_profile=0, mem_freq=mem_freq, device=dev)
+                clock.cores[lane] = core
+                clock.arm()
+                for i in cfg["interactions"]:
+                    idx = i % T
+                    out = yield from core.interact_steps(gt[idx], idx, step_cb=clock)
+                    if firsts[lane] is None:
+                        firsts[lane] = out.copy()
+                    if clock.done:
+                        break
+                del core
+        streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+        loops = [session_loop(lane) for lane in range(lanes)]
+        live = list(range(lanes))
+        while live:
+            for lane in list(live):
+                with torch.cuda.stream(streams[lane]):
+                    try:
+                        next(loops[lane])
+                    except StopIteration:
+                        live.remove(lane)
+        first = firsts[0]
     ops.PROFILE = None
     torch.cuda.synchronize()
     return clock, first
 
 
-def run_full_session(torch, shard, cfg, images, gt, prop, fuse, dev, mem_freq):
+def run_full_session(torch, shard, cfg, images, gt, prop, fuse, dev, mem_freq, lanes=1):
     """ONE complete session of the configuration (fresh InferenceCore over the HBM-resident clip, nothing pre-encoded), timed
     from before the first interact() to after the last, whatever `--steps/--warmup` selected for the headline window: the
     driver's `--steps 20 --warmup 5` window only sees plain propagation against a 2-6 frame bank, the session also holds the
     fused half and the bank's growth ("69 + 68").  Includes the per-interaction work outside the
-    do_pass loop (memorize of the interacted frame, final argmax + D2H of the masks)."""
+    do_pass loop (memorize of the interacted frame, final argmax + D2H of the masks).  lanes > 1: that many complete sessions in
+    flight, one HIP stream each, advanced in turn frame by frame; steps = the frames of all of them."""
     from mivos_amd.inference_core import InferenceCore
     T = images.shape[1]
-    core = InferenceCore(prop, fuse, images, cfg["objects"], mem_profile=0, mem_freq=mem_freq, device=dev)
+    cores = [InferenceCore(prop, fuse, images, cfg["objects"], mem_profile=0, mem_freq=mem_freq, device=dev) for _ in range(lanes)]
     torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     per = []
-    for i in cfg["interactions"]:
-        before = core.propagated_frames
-        core.interact(gt[i % T], i % T)
-        per.append(core.propagated_frames - before)
+    if lanes <= 1:
+        core = cores[0]
+        for i in cfg["interactions"]:
+            before = core.propagated_frames
+            core.interact(gt[i % T], i % T)
+            per.append(core.propagated_frames - before)
+    else:
+        def session(core):
+            for i in cfg["interactions"]:
+                yield from core.interact_steps(gt[i % T], i % T)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        loops = [session(c) for c in cores]
+        live = list(range(lanes))
+        while live:
+            for lane in list(live):
+                with torch.cuda.stream(streams[lane]):
+                    if next(loops[lane], "end") == "end":
+                        live.remove(lane)
+        per = [lanes * (T - 1)] + [lanes * (T - 2)] * (len(cfg["interactions"]) - 1)
     torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    n = core.propagated_frames
+    n = sum(c.propagated_frames for c in cores)
     return dict(value=round(n / dt, 3), unit="frames/s", ms_per_step=round(dt / n * 1e3, 3), steps=n, plain=per[0], fused=sum(per[1:]),
-                seconds=round(dt, 4), note="one whole session incl. memorize of the interacted frames and the final argmax + D2H; "
-                                           "untimed by --steps/--warmup")
+                seconds=round(dt, 4), sessions_in_flight=lanes,
+                note="whole session(s) incl. memorize of the interacted frames and the final argmax + D2H; untimed by --steps/--warmup")
 
 
 def self_spawn(args_list, n):
@@ -339,8 +392,9 @@ def main():
     ap.add_argument("--top-k", type=int, default=None)
     ap.add_argument("--mem-freq", type=int, default=5)
     ap.add_argument("--clips", type=int, default=474, help="config 4: how many of the 474 suite clips to run (default: all; ~4 min on one GPU)")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("MIVOS_SUITE_LANES", "1")),
-                    help="config 4: clips in flight per GPU, each on its own HIP stream (eval_suite.run_suite(lanes=...)); 1 = one clip at a time")
+    ap.add_argument("--lanes", type=int, default=None,
+                    help="clips / sessions in flight per GPU, each on its own HIP stream and advanced in turn frame by frame (eval_suite.run_suite(lanes=...), "
+                         "run_sessions(lanes=...)); 1 = one at a time.  Default: DEFAULT_LANES (env MIVOS_BENCH_LANES), config 5 always 1")
     ap.add_argument("--stub-engine", action="store_true",
                     help="PLUMBING TEST ONLY (tests/test_bench_multirank.py): config 4 with a numpy stand-in for InferenceCore, so that argument "
                          "parsing, self-spawn, sharding, the record gather and the JSON line can be exercised with world_size 2 on a machine "
@@ -362,6 +416,8 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_spawn(sys.argv[1:], args.gpus))
+    if args.lanes is None:
+        args.lanes = 1 if args.config in (5, "s2m", "train") else DEFAULT_LANES
 
     import torch
     torch.set_grad_enabled(False)
@@ -413,8 +469,13 @@ def main():
 
     if args.profile_every is None:
         args.profile_every = 21 if steps >= 400 else (7 if steps >= 40 else 3)
-    clock, masks_first = run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, warmup, steps, args.profile_every)
+    clock, masks_first = run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, warmup, steps, args.profile_every, lanes=args.lanes)
     elapsed = shard.max_over_ranks(clock.t1 - clock.t0, device=dev)
+    one_lane = None
+    if args.lanes > 1:                      # the same window with ONE session in flight (the figure of rounds 1-4), profile off
+        c1, _ = run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, warmup, steps, 0, lanes=1)
+        e1 = shard.max_over_ranks(c1.t1 - c1.t0, device=dev)
+        one_lane = dict(value=round(world * steps / e1, 3), unit="frames/s", ms_per_step=round(e1 / steps * 1e3, 3), steps=steps, warmup=warmup)
     recs = shard.gather_records([dict(rank=rank, steps=steps, seconds=round(clock.t1 - clock.t0, 6))])
     ranks_seen = shard.collective_ranks(dev)
     mem_gb = torch.cuda.max_memory_allocated() / 1e9
@@ -424,6 +485,13 @@ def main():
         full["seconds"] = round(shard.max_over_ranks(full["seconds"], device=dev), 4)
         full["value"] = round(world * full["steps"] / full["seconds"], 3)
         full["ms_per_step"] = round(full["seconds"] / full["steps"] * 1e3, 3)
+        if args.lanes > 1:                  # `lanes` complete sessions in flight; the single-session figure stays next to it
+            multi = run_full_session(torch, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, lanes=args.lanes)
+            multi["seconds"] = round(shard.max_over_ranks(multi["seconds"], device=dev), 4)
+            multi["value"] = round(world * multi["steps"] / multi["seconds"], 3)
+            multi["ms_per_step"] = round(multi["seconds"] / multi["steps"] * 1e3, 3)
+            multi["one_clip_in_flight"] = full
+            full = multi
 
     exact = None
     if exact_steps > 0 and rank == 0 and world == 1:
@@ -505,11 +573,13 @@ def main():
                data="synthetic",
                config=dict(workload=f"{cfg['name']} (BASELINE config {args.config}): {cfg['height']}x{cfg['width']} clip of {T} frames per GPU, {K} objects, "
                                     f"top_k={cfg['top_k']}, mem_freq={args.mem_freq}; session = interact at frames {inter} = {session} steps "
-                                    f"({T - 1} plain" + (f" + {T - 2} fused" if len(inter) > 1 else "") + f"); timed steps {warmup}..{warmup + steps} of the repeated session",
+                                    f"({T - 1} plain" + (f" + {T - 2} fused" if len(inter) > 1 else "") + f"); timed steps {warmup}..{warmup + steps} of the repeated session"
+                                    + (f"; {args.lanes} sessions in flight per GPU (one HIP stream each, advanced in turn frame by frame; a step is one propagated frame of either)" if args.lanes > 1 else ""),
                            baseline_config=args.config, objects=K, frames=T, height=cfg["height"], width=cfg["width"], top_k=cfg["top_k"],
                            mem_freq=args.mem_freq, session_steps=session, sessions_timed=round(steps / session, 3),
-                           prepaid_frames=0, lookahead_entries_dropped_at_t0=clock.dropped, parallelism=f"sequence-sharded x{world}"),
-               roofline=roof, full_session=full, conv_kernels=table, exact_f32=exact, hbm_peak_allocated_gb=round(mem_gb, 2), per_rank=recs, **ranks_seen)
+                           prepaid_frames=0, lookahead_entries_dropped_at_t0=clock.dropped, parallelism=f"sequence-sharded x{world}",
+                           clips_in_flight_per_gpu=args.lanes),
+               one_clip_in_flight=one_lane, roofline=roof, full_session=full, conv_kernels=table, exact_f32=exact, hbm_peak_allocated_gb=round(mem_gb, 2), per_rank=recs, **ranks_seen)
     if world == 1 and cpu_frames > 1:
         out["cpu_baseline"], out["parity"] = cpu_baseline(torch, cfg, images, gt, args.mem_freq, prop, fuse, dev, cpu_frames, args.cpu_fp64)
     else:
@@ -560,6 +630,8 @@ def bench_suite(args, torch, ops, shard, rank, world, dev):
     ES.run_suite([ES.ClipSpec(-1, 12, 3, 480, 853, 7)], factory, 0, 1, sync=sync)      # warm-up clip (untimed)
     sync(); shard.barrier(); sync()
     t0 = time.perf_counter()
+    if args.lanes is None:
+        args.lanes = DEFAULT_LANES
     lane_ctx = ES.stream_lanes(dev, args.lanes) if args.lanes > 1 and not args.stub_engine else None
     recs = ES.run_suite(specs, factory, rank, world, sync=sync, lanes=args.lanes, lane_ctx=lane_ctx)
     sync(); shard.barrier(); sync()

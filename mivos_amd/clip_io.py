@@ -76,6 +76,26 @@ def onehot_mask(label_map_u8, labels, device="cuda:0", resize_to=None):
     return out
 
 
+def onehot_masks(label_maps_u8, labels, device="cuda:0", resize_to=None):
+    """A clip's label maps uint8 [T,H,W] -> float one-hot [K+1,T,1,H',W'] (background first): ONE upload of the stack, one launch per
+    frame writing straight into the result (the loaders' `gt` is `[1:]` of it).  resize_to: the loader's nearest-neighbour resize."""
+    lab = torch.as_tensor(np.ascontiguousarray(label_maps_u8))
+    assert lab.dtype == torch.uint8 and lab.dim() == 3
+    T, H, W = lab.shape
+    oh, ow = (H, W) if resize_to is None else resize_to
+    dev = torch.device(device)
+    with ops.on_device(dev):
+        lab = lab.to(dev)
+        lv = torch.as_tensor(np.asarray(labels, dtype=np.uint8)).to(dev)
+        k = lv.numel()
+        out = torch.empty((k + 1, T, 1, oh, ow), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        for t in range(T):
+            check(lib.mivos_onehot_nearest(lab.data_ptr() + t * H * W, lv.data_ptr(), k, out.data_ptr() + 4 * t * oh * ow, H, W, oh, ow, T * oh * ow, ow, 0, 0,
+                                           ops._stream()))
+    return out
+
+
 def _png_chunk(tag, data):
     return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
 

@@ -387,7 +387,8 @@ static int launch_pp(ConvP &p, hipStream_t st) {
   const int nk = (p.Cin >> 5) * p.KH * p.KW, wgs = tiles_m * p.tiles_n, cap = lds <= 80 * 1024 ? 512 : 256;
   int slices = 1;
   static const int thr6 = getenv("MIVOS_PP_SPLIT_THR") ? atoi(getenv("MIVOS_PP_SPLIT_THR")) : 4;   // tuning only: split when fewer than thr6/6 of the workgroup slots are filled (A/B: +0.7 % end to end vs 2)
-  if (p.vec_epi && p.ws && wgs * 6 <= cap * thr6 && nk >= (wgs * 3 <= cap ? 16 : 96)) {   // nearly full grids: only very long K
+  static const int long_nk = getenv("MIVOS_PP_SPLIT_LONG_NK") ? atoi(getenv("MIVOS_PP_SPLIT_LONG_NK")) : 96;   // tuning only: K steps from which a grid that fills > 1/3 of the slots is still split
+  if (p.vec_epi && p.ws && wgs * 6 <= cap * thr6 && nk >= (wgs * 3 <= cap ? 16 : long_nk)) {   // nearly full grids: only very long K
     slices = cap / wgs < 2 ? 2 : cap / wgs;
     if (slices > 8) slices = 8;
     if (slices > nk / 8) slices = nk / 8;

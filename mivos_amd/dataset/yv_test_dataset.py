@@ -65,8 +65,7 @@ class YouTubeVOSTestDataset(Dataset):
         if on_gpu(self.device):
             from .. import clip_io
             images = clip_io.ingest_frames(frames, self.device, resize_to=new_size, padded=False)[0]
-            gt = torch.stack([clip_io.onehot_mask(m.astype(np.uint8), labels, self.device, resize_to=new_size)[1:, 0] for m in masks], 1)
-            gt = gt.unsqueeze(2)
+            gt = clip_io.onehot_masks(masks.astype(np.uint8), labels, self.device, resize_to=new_size)[1:]       # [K,T,1,H',W']
         else:
             images = F.interpolate(normalise_host(frames), size=new_size, mode="bicubic", align_corners=False)
             gt = torch.from_numpy(self.All_to_onehot(masks, labels)).float().unsqueeze(2)

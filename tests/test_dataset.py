@@ -57,8 +57,43 @@ def test_davis_loader_matches_the_reference_bitwise(golden_dir, g):
     _check_davis(ds, g)
     so = DAVISTestDataset(os.path.join(golden_dir, "mini_davis", "trainval"), single_object=True, target_name="blackswan")
     assert len(so) == 1 and torch.equal(so[0]["gt"], torch.from_numpy(g["davis_single_gt"]).float()) and so[0]["info"]["labels"] == [1]
-    with pytest.raises(NotImplementedError):
-        DAVISTestDataset(os.path.join(golden_dir, "mini_davis", "trainval"), resolution="1080p")
+
+
+def _full_resolution_root(golden_dir, tmp_path):
+    """A DAVIS root whose `Full-Resolution` trees are the mini dataset's 480p trees (symlinks): what the loader's non-480p mode reads."""
+    src = os.path.join(golden_dir, "mini_davis", "trainval")
+    root = tmp_path / "davis"
+    for sub in ("JPEGImages", "Annotations"):
+        os.makedirs(root / sub)
+        os.symlink(os.path.join(src, sub, "480p"), root / sub / "480p")
+        os.symlink(os.path.join(src, sub, "480p"), root / sub / "Full-Resolution")
+    os.symlink(os.path.join(src, "ImageSets"), root / "ImageSets")
+    return str(root)
+
+
+def test_davis_loader_resize_mode(golden_dir, tmp_path):
+    """davis_test_dataset.py:54-63, 98-99: any resolution but '480p' reads JPEGImages/<resolution> and brings the SHORT side to 600
+    (torchvision Resize(600): bicubic on the normalised frames, nearest on the one-hot masks)."""
+    rs = DAVISTestDataset.resized_size
+    assert rs(480, 854) == (600, 1067) and rs(1080, 1920) == (600, 1066) and rs(854, 480) == (1067, 600) and rs(600, 800) == (600, 800) and rs(128, 157) == (600, 735)
+    root = _full_resolution_root(golden_dir, tmp_path)
+    base = DAVISTestDataset(root, imset="2017/val.txt")[0]
+    big = DAVISTestDataset(root, imset="2017/val.txt", resolution="Full-Resolution")[0]
+    assert big["rgb"].shape == (5, 3, 600, 735) and big["gt"].shape == (2, 5, 1, 600, 735) and big["info"]["size_480p"] == base["info"]["size_480p"]
+    assert torch.equal(big["rgb"], torch.nn.functional.interpolate(base["rgb"], size=(600, 735), mode="bicubic", align_corners=False))
+    yy = (torch.arange(600) * (128 / 600)).floor().long().clamp(max=127)          # nearest: src = floor(dst * in / out)
+    xx = (torch.arange(735) * (157 / 735)).floor().long().clamp(max=156)
+    assert torch.equal(big["gt"][:, :, 0], base["gt"][:, :, 0][:, :, yy][:, :, :, xx])
+    assert set(big["gt"].unique().tolist()) <= {0.0, 1.0}
+
+
+@pytest.mark.gpu
+def test_davis_loader_resize_mode_on_the_gpu(golden_dir, tmp_path):
+    root = _full_resolution_root(golden_dir, tmp_path)
+    host = DAVISTestDataset(root, imset="2017/val.txt", resolution="Full-Resolution")[1]
+    dev = DAVISTestDataset(root, imset="2017/val.txt", resolution="Full-Resolution", device="cuda:0")[1]
+    assert dev["rgb"].is_cuda and dev["gt"].is_cuda and dev["rgb"].shape == host["rgb"].shape and dev["gt"].shape == host["gt"].shape
+    assert float((dev["rgb"].cpu() - host["rgb"]).abs().max()) < 5e-5 and torch.equal(dev["gt"].cpu(), host["gt"])
 
 
 def test_yv_loader_matches_the_reference_bitwise(golden_dir, g):

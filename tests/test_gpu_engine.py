@@ -334,6 +334,40 @@ def test_end_to_end_golden(nets, golden_dir, synthetic_states):
     assert core.propagated_frames == 6 + 5 + 4
 
 
+def test_gui_call_pattern_under_autocast_golden(nets, golden_dir):
+    """How the reference's GUI drives the processor (interactive_gui.py:550, 616, 626, 636-642, 889-897, 955-960, all inside
+    `torch.cuda.amp.autocast`, :990), replayed PyQt-free by oracle/gui_replay.py on the engine: `prob[:, i].clone()` as an edit's start,
+    `update_mask_only` after every stroke read back through `np_masks[i]`, in-place `masks[i].zero_()` / `np_masks[i].fill(0)`, the
+    `current_mask` alias, progress callbacks, re-interaction after a reset - against what the UNMODIFIED reference InferenceCore produced
+    for the same scripted session (tests/golden/gui_small.npz, oracle/make_golden_gui.py)."""
+    from oracle import gui_replay as G
+    prop, fuse = nets
+    with np.load(os.path.join(golden_dir, "gui_small.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    c = json.loads(str(g["config"]))
+    assert c == G.SESSION
+    images, gt = O.synthetic_clip(c["t"], c["h"], c["w"], c["k"], c["seed"])
+    with torch.cuda.amp.autocast(enabled=True):
+        core = InferenceCore(prop, fuse, images, c["k"], mem_profile=0, mem_freq=c["mem_freq"], device=DEV)
+        gui, local = G.scripted_session(core, gt)
+    assert [n for n, _ in gui.events] == [str(n) for n in g["event_names"]]
+    assert [p[1] if p[0] == "total" else -1 for p in gui.progress] == g["progress"].tolist()
+    assert np.array_equal(gui.events[0][1], g["current_mask_0"])       # the first event only holds the argmax of a one-hot input: exact
+    for i, (name, cur) in enumerate(gui.events):
+        ref = g[f"current_mask_{i}"]
+        assert cur.shape == ref.shape and cur.dtype == np.uint8
+        iou = mean_iou(cur, ref, c["k"])
+        print(f"event {i} {name}: IoU vs the reference's GUI state {iou:.6f}, mismatching px {int((cur != ref).sum())}")
+        assert iou >= 0.999, (i, name, iou)
+    assert core.prob.dtype == torch.float32 and core.masks.dtype == torch.uint8              # autocast changed no public dtype
+    assert float((core.prob.cpu() - T(g["final_prob"])).abs().max()) < 5e-3
+    assert mean_iou(core.np_masks, g["final_np_masks"], c["k"]) >= 0.999
+    assert np.array_equal(local["image"], g["local_image"]) and tuple(local["pad"]) == tuple(int(v) for v in g["local_pad"])
+    assert float(np.abs(local["prev_soft_mask"] - g["local_prev_soft_mask"]).max()) < 5e-3
+    # the reset reached the processor's own buffers, and the alias the GUI relies on holds: interact returns np_masks itself
+    assert gui.current_mask is not None and core.interact(gui.processor.prob[:, 1].clone(), 1) is core.np_masks
+
+
 def test_update_mask_only_golden(nets, golden_dir):
     """InferenceCore.update_mask_only (reference inference_core.py:273-293; 5 of the 8 interactions of a DAVIS session,
     davis_processor.py:75-82) against the unmodified reference's results (tests/golden/update_small.npz): the argmax over the K+1
