@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
                 ("y2_nstride", i64), ("y2_pstride", i64), ("res_nstride", i64), ("res_pstride", i64),
                 ("workspace", vp), ("workspace_bytes", i64),
                 ("x_rstride", i64), ("y_rstride", i64), ("res_rstride", i64),
-                ("x_border", i32), ("x_format", i32), ("y_format", i32), ("res_format", i32), ("dilation", i32)]
+                ("x_border", i32), ("x_format", i32), ("y_format", i32), ("res_format", i32), ("dilation", i32), ("chip_share", i32)]
 
 
 class InterleaveDesc(C.Structure):

@@ -17,6 +17,7 @@ struct ConvP {
   int x_border;                        // zero pixels guaranteed around every input image (precision 2 needs >= pad)
   int y_fmt, r_fmt;                    // 0: fp32, 1: SH32 (fp16 hi | lo lines per 32 channels, conv_f16x3_dma.hip)
   int dil;                             // tap spacing (atrous convolution), >= 1
+  int share;                           // launch streams the caller keeps busy on this GPU (>= 1): geometry hint, never changes results
 };
 
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));

@@ -384,7 +384,8 @@ static int launch_pp(ConvP &p, hipStream_t st) {
   const long long w_bytes = ROWB + (long long)(p.Cin >> 5) * p.KH * p.KW * p.Cout * ROWB;
   if (x_bytes >= 0x7ff00000ll || w_bytes >= 0x7ff00000ll) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d (SH32 input): tensor larger than 2 GB");
   // split-K when the tile grid cannot fill the chip and K is long (30x54 layers at small batch)
-  const int nk = (p.Cin >> 5) * p.KH * p.KW, wgs = tiles_m * p.tiles_n, cap = lds <= 80 * 1024 ? 512 : 256;
+  static const int share_cap = getenv("MIVOS_PP_SHARE_CAP") ? atoi(getenv("MIVOS_PP_SHARE_CAP")) : 1;   // tuning only: 0 = ignore chip_share
+  const int nk = (p.Cin >> 5) * p.KH * p.KW, wgs = tiles_m * p.tiles_n, cap = (lds <= 80 * 1024 ? 512 : 256) / (share_cap && p.share > 1 ? p.share : 1);
   int slices = 1;
   static const int thr6 = getenv("MIVOS_PP_SPLIT_THR") ? atoi(getenv("MIVOS_PP_SPLIT_THR")) : 4;   // tuning only: split when fewer than thr6/6 of the workgroup slots are filled (A/B: +0.7 % end to end vs 2)
   static const int long_nk = getenv("MIVOS_PP_SPLIT_LONG_NK") ? atoi(getenv("MIVOS_PP_SPLIT_LONG_NK")) : 96;   // tuning only: K steps from which a grid that fills > 1/3 of the slots is still split

@@ -1471,7 +1471,13 @@ static long long q256_min() {
     // ROCm 7.2.  A library built with another hipcc keeps the kernel for callers who ask for it (mivos_memory_read_set_q256_min, the env
     // variable above) but does not select it on its own: deep banks then run on the 128-query kernel, whose requests are counted the same
     // way but whose candidate handling has no loads the compiler could reorder against them.
-    if (!Q256_TOOLCHAIN_VALIDATED && !getenv("MIVOS_MEMREAD_Q256_MIN")) v = 0x7fffffffffffffffLL;
+    if (!Q256_TOOLCHAIN_VALIDATED && !getenv("MIVOS_MEMREAD_Q256_MIN")) {
+      v = 0x7fffffffffffffffLL;
+      // one line, once per process: a large, otherwise invisible difference in speed on deep banks (config 5: x 1.2)
+      fprintf(stderr, "mivos_hip: built with HIP %d.%d - the 256-query memory-read kernel is validated on HIP 7.2 only and is not selected automatically; "
+                      "banks >= 200 k positions run on the 128-query kernel (set MIVOS_MEMREAD_Q256_MIN=200000 to use it anyway)\n",
+              HIP_VERSION_MAJOR, HIP_VERSION_MINOR);
+    }
     g_q256_min.store(v, std::memory_order_relaxed);
   }
   return v;

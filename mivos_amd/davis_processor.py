@@ -22,8 +22,8 @@ class DAVISProcessor:
         self.s2m_net.refresh_plan_if_stale()                    # packed weights follow parameters changed since the last clip
         _, self.pad = pad_divide_by(images[:, :1], 16, images.shape[-2:])
         self.t = images.shape[1]
-        self.h, self.w = images.shape[-2:]                      # true dimensions (the reference overwrites them with the padded
-        self.k = num_objects                                    # ones, davis_processor.py:28-32; scribbles2mask needs the true)
+        self.h, self.w = images.shape[-2:]                      # true dimensions (the reference overwrites them with the padded ones,
+        self.k = num_objects                                    # davis_processor.py:28-32; its scribbles are rasterised on THAT canvas: to_mask)
         self.interacted_count = 0
         self.davis_schedule = [2, 5, 7]
         self.processor = InferenceCore(prop_net, fuse_net, images, num_objects, mem_profile=0, device=device)
@@ -83,6 +83,14 @@ class DAVISProcessor:
         mask, idx = self.to_mask(scribble)
         return self._advance(mask, idx)
 
+    def scribble_canvas(self):
+        """(rows, columns) on which a caller of interact_scribble_mask must rasterise normalised scribble paths to reproduce
+        interact(): the PADDED frame (nh, nw) - see to_mask."""
+        return self.nh, self.nw
+
     def interact_scribble_mask(self, scr_mask, idx):
-        """interact() for callers that rasterise the scribbles themselves."""
+        """interact() for callers that rasterise the scribbles themselves.  For the reference's results the label map has to be
+        rasterised on `scribble_canvas()` = the padded (nh, nw) frame (what to_mask does, like davis_processor.py:38-50); a map of the
+        true (h, w) frame is accepted too and is taken as is - its strokes then sit where the caller put them, up to 1.2 % (854 -> 864
+        columns) away from where interact() would put the same normalised paths."""
         return self._advance(self.mask_from_scribble_mask(scr_mask, idx), idx)

@@ -85,6 +85,20 @@ def run_suite(specs, engine_factory, rank=0, world=1, sync=None, on_clip=None, l
     if sync:
         sync()
     t_start = time.perf_counter()
+    share = getattr(lane_ctx, "chip_share", None)           # stream_lanes: tells the convolutions how many streams share the GPU
+    with (share(lanes) if share else contextlib.nullcontext()):
+        _advance_lanes(specs, engine_factory, rank, lanes, lane_ctx, on_clip, todo, active, records)
+    if sync:
+        sync()
+    wall = time.perf_counter() - t_start
+    out = [records[specs[i].clip_id] for i in parts[rank]]
+    in_flight = sum(r["seconds"] for r in out)
+    for r in out:
+        r["seconds"] = r["seconds"] * wall / in_flight if in_flight > 0 else 0.0
+    return out
+
+
+def _advance_lanes(specs, engine_factory, rank, lanes, lane_ctx, on_clip, todo, active, records):
     while todo or active:
         for lane in range(lanes):
             with lane_ctx(lane):
@@ -104,21 +118,19 @@ def run_suite(specs, engine_factory, rank=0, world=1, sync=None, on_clip=None, l
                     records[spec.clip_id] = dict(clip=spec.clip_id, rank=rank, frames=spec.frames - 1, objects=spec.objects,
                                                  seconds=time.perf_counter() - t0, checksum=mask_checksum(masks), lanes=lanes)
                     del active[lane]
-    if sync:
-        sync()
-    wall = time.perf_counter() - t_start
-    out = [records[specs[i].clip_id] for i in parts[rank]]
-    in_flight = sum(r["seconds"] for r in out)
-    for r in out:
-        r["seconds"] = r["seconds"] * wall / in_flight if in_flight > 0 else 0.0
-    return out
 
 
 def stream_lanes(device, lanes):
-    """`lane_ctx` of run_suite for a GPU: one HIP stream per lane (created once), entered with torch.cuda.stream."""
+    """`lane_ctx` of run_suite for a GPU: one HIP stream per lane (created once), entered with torch.cuda.stream; its `chip_share`
+    attribute (ops.chip_share) tells every convolution launched inside how many streams share the chip."""
     import torch
+    from . import ops
     streams = [torch.cuda.Stream(device=device) for _ in range(lanes)]
-    return lambda lane: torch.cuda.stream(streams[lane])
+
+    def ctx(lane):
+        return torch.cuda.stream(streams[lane])
+    ctx.chip_share = ops.chip_share
+    return ctx
 
 
 # ---- the same loop over a real dataset (mivos_amd/dataset/*: the reference's test-time loaders) -----------------------------------

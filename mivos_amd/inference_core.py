@@ -295,11 +295,12 @@ class InferenceCore:
                  (side, self._pass_steps(plans[1], rows, key_v, idx, step_cb=step_cb))]
         for t in (rows, key_v):
             t.record_stream(side)
-        while lanes:
-            for lane in list(lanes):
-                with torch.cuda.stream(lane[0]):
-                    if next(lane[1], None) is None:
-                        lanes.remove(lane)
+        with ops.chip_share(2 * ops.CHIP_SHARE):
+            while lanes:
+                for lane in list(lanes):
+                    with torch.cuda.stream(lane[0]):
+                        if next(lane[1], None) is None:
+                            lanes.remove(lane)
         main.wait_stream(side)
 
     @_on_core_device

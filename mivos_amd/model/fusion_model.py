@@ -96,6 +96,17 @@ def multistep_state_dict(milestones, gamma, lr_initial, last_epoch):
                 _step_count=int(last_epoch) + 1, _get_lr_called_within_step=False, _last_lr=[float(lr)])
 
 
+def get_iou_hook(values):                   # losses.py:8-9
+    return "iou/iou", (values["hide_iou/i"] + 1) / (values["hide_iou/u"] + 1)
+
+
+def get_sec_iou_hook(values):               # losses.py:11-12
+    return "iou/sec_iou", (values["hide_iou/sec_i"] + 1) / (values["hide_iou/sec_u"] + 1)
+
+
+iou_hooks = [get_iou_hook, get_sec_iou_hook]
+
+
 class Integrator:
     """Running means of the logged losses (reference util/log_integrator.py:10-78, the part FusionModel uses): add_dict per
     iteration, finalize(prefix, it) averages, sums over the ranks (one reduce of a scalar per key) and hands rank 0's logger
@@ -172,6 +183,7 @@ class FusionModel:
         import time
         self.last_time = time.time()
         self.train_integrator = Integrator(logger, distributed=self.distributed, local_rank=local_rank, world_size=world_size)
+        self.train_integrator.add_hook(iou_hooks)                               # fusion_model.py:38: train/iou/iou, train/iou/sec_iou
         self.val_integrator = Integrator(logger, distributed=self.distributed, local_rank=local_rank, world_size=world_size)
         self.report_interval, self.save_im_interval, self.save_model_interval = 100, 500, 5000
         if para.get("debug"):
@@ -306,6 +318,12 @@ class FusionModel:
                     this_p = frac
                 losses = {"total_loss": per_sample.sum() / B, "p": this_p}
                 if self._do_log:
+                    # losses.py:66-73: intersection / union sums of the two objects' masks against their ground truth (a logging metric:
+                    # two compares and four reductions per iteration, no host synchronisation before finalize)
+                    m = out["mask"]
+                    for tag, seg, gt in (("", m[:, 1:2] > 0.5, d["gt"] > 0.5), ("sec_", m[:, 2:3] > 0.5, d["gt2"] > 0.5)):
+                        losses[f"hide_iou/{tag}i"] = (seg & gt).float().sum()
+                        losses[f"hide_iou/{tag}u"] = (seg | gt).float().sum()
                     self.integrator.add_dict(losses)                   # (image dumps of the reference's logger, :99-113, are not reproduced)
             if self._is_train:
                 import time

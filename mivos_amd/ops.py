@@ -71,6 +71,17 @@ def single_stream_region():
         _PUBLISH[0] = old
 
 
+@contextlib.contextmanager
+def chip_share(n):
+    """Inside: convolutions are told that `n` independent launch streams share this GPU (CHIP_SHARE -> mivos_conv_desc.chip_share)."""
+    global CHIP_SHARE
+    old, CHIP_SHARE = CHIP_SHARE, max(1, int(n))
+    try:
+        yield
+    finally:
+        CHIP_SHARE = old
+
+
 def publish_constants():
     """Called once after device-resident constants (packed weights, folded BN vectors, compiled plans) were produced by launches on the
     current stream: waits for the device, so that launches on ANY stream may read them afterwards without a stream dependency (two
@@ -252,6 +263,8 @@ import collections
 
 _act_scratch = collections.OrderedDict()
 ACT_SCRATCH_ENTRIES = 256   # scratch buffers kept per process (least recently used ones go first)
+CHIP_SHARE = 1          # independent launch streams the caller keeps busy on this GPU (lanes of run_suite / bench, the two passes of an interaction):
+                        # passed to every convolution as mivos_conv_desc.chip_share (launch-geometry hint; results do not depend on it)
 COUT1_PROJECTION = True # one-output-channel 3x3 layers as a 1x1 projection to nine tap products + tap_sum9 (False: the generic kernels; diagnostics)
 USE_ACT_PATH = True     # run conv -> conv edges on the LDS-DMA kernels (needs CONV_PRECISION == "f16x3")
 
@@ -369,6 +382,7 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
     d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = n, h, w, cin, L.cout, L.k, L.k
     d.stride, d.pad, d.Ho, d.Wo, d.split, d.dilation = L.stride, L.pad, ho, wo, L.split, L.dil
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)
+    d.chip_share = CHIP_SHARE
     assert tuple(out.shape) == (n, ho, wo, L.split), (out.shape, (n, ho, wo, L.split))
     if isinstance(out, Act):
         d.y, d.y_format = out.interior_ptr(), 1

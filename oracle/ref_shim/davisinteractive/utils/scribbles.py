@@ -1,7 +1,9 @@
 """scribbles2mask of the stand-in `davisinteractive` (see the package docstring).  Interface of the framework's function:
 scribbles dict {'sequence': str, 'scribbles': [per frame: [{'path': [[x, y], ...] in [0, 1], 'object_id': int, ...}]]},
 output_resolution (H, W) -> int array [n_frames, H, W], `default_value` (-1) where no scribble passes, the object id along the
-scribble lines (points scaled to pixel coordinates, consecutive points joined by Bresenham segments)."""
+scribble lines (points scaled to pixel coordinates by (W - 1, H - 1) and TRUNCATED to integers like the framework's
+`path.astype(int)`, consecutive points joined by Bresenham segments).  A stand-in written from the framework's documented behaviour, not
+a byte-exact copy: the entry-script goldens pin the reference's code given THIS rasteriser on both sides."""
 import numpy as np
 
 
@@ -30,7 +32,7 @@ def scribbles2mask(scribbles, output_resolution, bresenham=True, default_value=-
     for f, lines in enumerate(frames):
         for line in lines:
             path = np.asarray(line["path"], dtype=np.float64)
-            px = np.clip(np.round(path * np.array([w - 1, h - 1])).astype(np.int64), 0, [w - 1, h - 1])
+            px = np.clip((path * np.array([w - 1, h - 1])).astype(np.int64), 0, [w - 1, h - 1])
             pts = [tuple(px[0])]
             for a, b in zip(px[:-1], px[1:]):
                 pts += _bresenham(int(a[0]), int(a[1]), int(b[0]), int(b[1]))[1:] if bresenham else [tuple(b)]

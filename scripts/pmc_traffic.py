@@ -9,7 +9,11 @@ both counters are in KiB.  Values are averaged per dispatch of each kernel."""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_fingerprint import csrc_fingerprint  # noqa: E402
 
 
 def per_kernel(path, counter):
@@ -34,6 +38,7 @@ def main(fetch_csv, write_csv, out_json):
         print(f"{short[:72]:72s} {n:5d} {2 * f * 1024 / 1e6:10.1f} {w * 1024 / 1e6:10.1f}")
         out[short] = dict(launches=n, read_bytes_per_launch=2 * f * 1024, write_bytes_per_launch=w * 1024,
                           fetch_size_raw_kb=f, write_size_raw_kb=w)
+    out["_meta"] = dict(csrc_fingerprint=csrc_fingerprint(), counters="FETCH_SIZE x 2 (gfx950 correction) and WRITE_SIZE, separate rocprofv3 --pmc passes, KiB -> bytes")
     json.dump(out, open(out_json, "w"), indent=1)
 
 

@@ -63,5 +63,14 @@ int main() {
   run("C=0, 1 + 2^-26 (RNE: 1, round up: 1+2^-23)", a, b, 0.f, 1.0 + ldexp(1.0, -26));
   zero(); a[0] = 1.f; b[0] = 1.f; a[1] = 1.f * ldexpf(1.f, -12); b[1] = ldexpf(1.f, -12); a[2] = 1.f * ldexpf(1.f, -13); b[2] = ldexpf(1.f, -13);
   run("C=0, 1 + 2^-24 + 2^-26 (RNE: 1+2^-23; sticky lost: 1)", a, b, 0.f, 1.0 + ldexp(1.0, -24) + ldexp(1.0, -26));
+  // fp16 subnormal operands (|v| < 2^-14): the lo halves of the f16x3 split are subnormal for every |x| < 2^-3
+  zero(); a[0] = ldexpf(1.f, -20); b[0] = 1.f;
+  run("C=0, subnormal a = 2^-20 times 1 (kept: 2^-20, flushed: 0)", a, b, 0.f, ldexp(1.0, -20));
+  zero(); a[0] = 1.f; b[0] = ldexpf(410.f, -24);
+  run("C=0, 1 times subnormal b = 410 * 2^-24 (lo of x = 0.1)", a, b, 0.f, 410.0 * ldexp(1.0, -24));
+  zero(); a[0] = 0.0999755859375f; b[0] = 1.f; a[1] = ldexpf(410.f, -24); b[1] = 1.f;
+  run("C=0, hi(0.1) + lo(0.1) as two products (kept: 0.1)", a, b, 0.f, 0.0999755859375 + 410.0 * ldexp(1.0, -24));
+  zero(); a[0] = ldexpf(1.f, -20); b[0] = ldexpf(1.f, -4);
+  run("C=0, subnormal 2^-20 times 2^-4 (product 2^-24)", a, b, 0.f, ldexp(1.0, -24));
   return 0;
 }

@@ -214,7 +214,9 @@ def test_checkpoint_round_trip_and_reference_layout(tmp_path):
     for it in range(4):
         a.do_pass(dict(data), it)                                   # it = 2: report + periodic checkpoint (it % interval == 0 and it != 0)
     assert os.path.isfile(str(tmp_path / "run" / "fusion_2.pth")) and os.path.isfile(str(tmp_path / "run" / "fusion_checkpoint.pth"))
-    assert [m[:2] for m in log.metrics if m[3] == 2] == [("train", "time"), ("train", "total_loss"), ("train", "p")] and log.scalars[0][0] == "train/lr"
+    assert [m[:2] for m in log.metrics if m[3] == 2] == [("train", "time"), ("train", "total_loss"), ("train", "p"), ("train", "iou/iou"),
+                                                          ("train", "iou/sec_iou")] and log.scalars[0][0] == "train/lr"      # fusion_model.py:38 + losses.py:8-16
+    assert all(0.0 < m[2] <= 1.0 for m in log.metrics if m[1].startswith("iou/"))
     a.val().do_pass(dict(data), 4)
     a.finalize_val(4)
     assert ("val", "total_loss") in [m[:2] for m in log.metrics] and a.val_integrator.values == {}

@@ -385,32 +385,59 @@ def test_bench_roofline_helpers_on_committed_profiles():
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    t = bench.pmc_traffic(3, "conv_f16x3_pp_kernel<128,128,2,4,0>")
-    assert t and "config3" in t["source"] and t["bytes_per_launch"] == t["read"] + t["write"] and t["launches_profiled"] > 1000
-    assert bench.pmc_traffic(3, "conv_f16x3_pp_kernel<128,128,2,4,9>") is None             # another instantiation: no figure
-    assert bench.pmc_traffic(2, "memread_select256_kernel") is None                        # no pass of that kernel in that config
-    t5 = bench.pmc_traffic(5, "memread_select256_kernel")
-    assert t5 and "config5" in t5["source"] and "note" in t5                               # a single-read pass says so
-    u = bench.pmc_mfma_util(3, "conv_f16x3_pp_kernel<128,256,2,4,0>")
-    assert u and 40 < u["mean_pct"] < 90 and u["min_pct"] <= u["mean_pct"] <= u["max_pct"]
-    assert bench.pmc_mfma_util(5, "memread_select256_kernel")["dispatches"] >= 1
-    assert bench.pmc_mfma_util(4, "memread_select256_kernel") is None
+    # committed records are used only for the kernels they were read from (`_meta.csrc_fingerprint`, scripts/csrc_fingerprint.py): work
+    # on copies stamped with this tree's fingerprint, then on an unstamped copy
+    import glob
+    import json
+    import shutil
+    import tempfile
+    src = bench.PROFILES_DIR
+    tmp = tempfile.mkdtemp(prefix="mivos_profiles_")
+    try:
+        for f in glob.glob(os.path.join(src, "r04*config*pmc_traffic.json")) + glob.glob(os.path.join(src, "r04*config*mfma_util.json")) + \
+                glob.glob(os.path.join(src, "r03h*config5*.json")) + glob.glob(os.path.join(src, "r03f*config5*.json")):
+            table = json.load(open(f))
+            table["_meta"] = dict(csrc_fingerprint=bench._csrc_fingerprint())
+            json.dump(table, open(os.path.join(tmp, os.path.basename(f)), "w"))
+        bench.PROFILES_DIR = tmp
+        t = bench.pmc_traffic(3, "conv_f16x3_pp_kernel<128,128,2,4,0>")
+        assert t and "config3" in t["source"] and t["bytes_per_launch"] == t["read"] + t["write"] and t["launches_profiled"] > 1000
+        assert bench.pmc_traffic(3, "conv_f16x3_pp_kernel<128,128,2,4,9>") is None             # another instantiation: no figure
+        assert bench.pmc_traffic(2, "memread_select256_kernel") is None                        # no pass of that kernel in that config
+        t5 = bench.pmc_traffic(5, "memread_select256_kernel")
+        assert t5 and "config5" in t5["source"] and "note" in t5                               # a single-read pass says so
+        u = bench.pmc_mfma_util(3, "conv_f16x3_pp_kernel<128,256,2,4,0>")
+        assert u and 40 < u["mean_pct"] < 90 and u["min_pct"] <= u["mean_pct"] <= u["max_pct"]
+        assert bench.pmc_mfma_util(5, "memread_select256_kernel")["dispatches"] >= 1
+        assert bench.pmc_mfma_util(4, "memread_select256_kernel") is None
+        # a record read from other kernels (no or another fingerprint) answers with a marker, never with numbers
+        name = os.path.basename(t["source"])
+        table = json.load(open(os.path.join(tmp, name)))
+        table["_meta"] = dict(csrc_fingerprint="0" * 16)
+        json.dump(table, open(os.path.join(tmp, name), "w"))
+        stale = bench.pmc_traffic(3, "conv_f16x3_pp_kernel<128,128,2,4,0>")
+        assert stale["stale"] is True and stale["source"] == name and "bytes_per_launch" not in stale and stale["tree"] == bench._csrc_fingerprint()
+        table["_meta"] = dict(csrc_fingerprint=bench._csrc_fingerprint())
+        json.dump(table, open(os.path.join(tmp, name), "w"))
 
-    class Ev:
-        def __init__(self, t):
-            self.t = t
+        class Ev:
+            def __init__(self, t):
+                self.t = t
 
-        def elapsed_time(self, other):
-            return other.t - self.t                                                       # milliseconds, like torch.cuda.Event
+            def elapsed_time(self, other):
+                return other.t - self.t                                                       # milliseconds, like torch.cuda.Event
 
-    samples = [(20, 12e9, Ev(0.0), Ev(0.05), (8100, 256, 256, 3, 1, 0)), (21, 50e9, Ev(0.0), Ev(0.25), (129600, 256, 256, 3, 1, 1)),
-               (90, 28e9, Ev(0.0), Ev(0.32), (5, 11340, 1620, 50, 36e6)), (91, 0.0, Ev(0.0), Ev(0.08), (5, 1620, 50, 8e8))]
-    roof, aff, table = bench.kernel_rooflines(samples, 0.0, 3, "memread_select_kernel<0,false,true>")
-    assert roof["kernel"] == "conv_f16x3_pp_kernel<128,256,2,4,0>" and abs(roof["achieved"] - 200.0) < 1e-6 and abs(roof["frac"] - 200.0 / 833.3) < 1e-3
-    assert roof["traffic"]["source"].endswith("pmc_traffic.json") and roof["mfma_util_pmc"]["source"].endswith("mfma_util.json")
-    assert abs(aff["achieved"] - 87.5) < 1e-6 and abs(aff["frac"] - 87.5 / 833.3) < 1e-3 and "frac_of_f32_mfma_peak" not in aff and aff["finalize"]["avg_launch_us"] == 80.0
-    assert set(table) == {"conv_f16x3_pp_kernel<128,128,2,4,0>", "conv_f16x3_pp_kernel<128,256,2,4,0>", "memread_select_kernel", "memread_finalize_kernel"}
-    assert bench.kernel_rooflines([], 0.0, 3, None) == (None, None, {})
+        samples = [(20, 12e9, Ev(0.0), Ev(0.05), (8100, 256, 256, 3, 1, 0)), (21, 50e9, Ev(0.0), Ev(0.25), (129600, 256, 256, 3, 1, 1)),
+                   (90, 28e9, Ev(0.0), Ev(0.32), (5, 11340, 1620, 50, 36e6)), (91, 0.0, Ev(0.0), Ev(0.08), (5, 1620, 50, 8e8))]
+        roof, aff, table = bench.kernel_rooflines(samples, 0.0, 3, "memread_select_kernel<0,false,true>")
+        assert roof["kernel"] == "conv_f16x3_pp_kernel<128,256,2,4,0>" and abs(roof["achieved"] - 200.0) < 1e-6 and abs(roof["frac"] - 200.0 / 833.3) < 1e-3
+        assert roof["traffic"]["source"].endswith("pmc_traffic.json") and roof["mfma_util_pmc"]["source"].endswith("mfma_util.json")
+        assert abs(aff["achieved"] - 87.5) < 1e-6 and abs(aff["frac"] - 87.5 / 833.3) < 1e-3 and "frac_of_f32_mfma_peak" not in aff and aff["finalize"]["avg_launch_us"] == 80.0
+        assert set(table) == {"conv_f16x3_pp_kernel<128,128,2,4,0>", "conv_f16x3_pp_kernel<128,256,2,4,0>", "memread_select_kernel", "memread_finalize_kernel"}
+        assert bench.kernel_rooflines([], 0.0, 3, None) == (None, None, {})
+    finally:
+        bench.PROFILES_DIR = src
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def test_hi_first_bound_model():
