@@ -48,7 +48,11 @@ VARIANT_NAMES = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<64,6
 # clips in flight per GPU (see --lanes): a 480p frame of 1-5 objects leaves most of the 256 CUs idle at the 1/16-resolution layers, a second
 # clip on a second stream fills them (profiles/r05a_suite_lanes_ab.txt: config 4 199.7 -> 233.3 -> 241.4 frames/s at 1 / 2 / 3 lanes, identical masks)
 GATE_FACTOR = 2.0        # tests/test_gpu_engine.py::ARBITRATION_FACTOR
-DEFAULT_LANES = int(os.environ.get("MIVOS_BENCH_LANES", "1"))
+# profiles/r05c_lanes_ab.txt: config 3 (5 objects) 206 -> 236 -> 221 frames/s at 1 / 2 / 3 lanes, config 2 (1 object) 404 -> 511 -> 593 -> 489 at 1..4,
+# config 4 (1-5 objects) 200 -> 237 -> 247 -> 242
+DEFAULT_LANES = {2: 3, 3: 2, 4: 3}
+if os.environ.get("MIVOS_BENCH_LANES"):
+    DEFAULT_LANES = {c: int(os.environ["MIVOS_BENCH_LANES"]) for c in (2, 3, 4)}
 CONFIGS = {
     2: dict(name="davis480p_single_object", height=480, width=854, frames=70, objects=1, top_k=20, interactions=(0,)),
     3: dict(name="davis480p_multiobject_fusion", height=480, width=854, frames=70, objects=5, top_k=50, interactions=(0, -1)),
@@ -439,7 +443,7 @@ def main():
     ap.add_argument("--clips", type=int, default=474, help="config 4: how many of the 474 suite clips to run (default: all; ~4 min on one GPU)")
     ap.add_argument("--lanes", type=int, default=None,
                     help="clips / sessions in flight per GPU, each on its own HIP stream and advanced in turn frame by frame (eval_suite.run_suite(lanes=...), "
-                         "run_sessions(lanes=...)); 1 = one at a time.  Default: DEFAULT_LANES (env MIVOS_BENCH_LANES), config 5 always 1")
+                         "run_sessions(lanes=...)); 1 = one at a time.  Default: DEFAULT_LANES per config (2 for config 3, 3 for configs 2 / 4; env MIVOS_BENCH_LANES), everything else 1")
     ap.add_argument("--stub-engine", action="store_true",
                     help="PLUMBING TEST ONLY (tests/test_bench_multirank.py): config 4 with a numpy stand-in for InferenceCore, so that argument "
                          "parsing, self-spawn, sharding, the record gather and the JSON line can be exercised with world_size 2 on a machine "
@@ -462,7 +466,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_spawn(sys.argv[1:], args.gpus))
     if args.lanes is None:
-        args.lanes = 1 if args.config in (5, "s2m", "train") else DEFAULT_LANES
+        args.lanes = DEFAULT_LANES.get(args.config, 1)
 
     import torch
     torch.set_grad_enabled(False)
@@ -680,8 +684,6 @@ def bench_suite(args, torch, ops, shard, rank, world, dev):
     ES.run_suite([ES.ClipSpec(-1, 12, 3, 480, 853, 7)], factory, 0, 1, sync=sync)      # warm-up clip (untimed)
     sync(); shard.barrier(); sync()
     t0 = time.perf_counter()
-    if args.lanes is None:
-        args.lanes = DEFAULT_LANES
     lane_ctx = ES.stream_lanes(dev, args.lanes) if args.lanes > 1 and not args.stub_engine else None
     recs = ES.run_suite(specs, factory, rank, world, sync=sync, lanes=args.lanes, lane_ctx=lane_ctx)
     sync(); shard.barrier(); sync()

@@ -95,9 +95,10 @@ typedef struct {
   int32_t dilation;    /* spacing of the kernel taps (0 or 1: dense).  DeepLab's atrous convolutions (model/s2m/_deeplab.py:
                           110-118, s2m_resnet.py:17-20) use 2 / 6 / 12 / 18 with pad == dilation; precision 0 / 1 only.       */
   int32_t chip_share;  /* how many independent launch streams the caller keeps busy on this GPU (0 or 1: this launch has the
-                          chip to itself).  A hint for the launch geometry only - results are identical: with n > 1 the split-K /
-                          tile heuristics of precision 2 count on 1/n of the workgroup slots (a second clip's launches fill the
-                          rest; splitting K to fill them would only add partial-sum traffic).                                   */
+                          chip to itself).  A hint for the launch geometry only: with n > 1 the split-K heuristics of precision 2
+                          count on 1/n of the workgroup slots (a second clip's launches fill the rest; splitting K to fill them
+                          would only add partial-sum traffic).  Results are the same up to the fp32 summation order a different
+                          number of K slices implies (rounding level, like a different batch size).                            */
 } mivos_conv_desc;
 
 int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream);

@@ -56,7 +56,7 @@ def run_suite(specs, engine_factory, rank=0, world=1, sync=None, on_clip=None, l
     lane i inside the context `lane_ctx(i)` - a HIP stream per lane (`stream_lanes`), so that the under-filled launches of one
     clip (a 480p frame of 1-5 objects fills a fraction of the 256 CUs at the 1/16-resolution layers) run beside the other's.
     Clips stay independent - no tensor is shared between lanes but the read-only weights - and the results are bit-identical
-    to lanes = 1 (tests).  A clip's `seconds` is then its share of the rank's wall clock (its own in-flight time, scaled so
+    to lanes = 1 run with the same launch-geometry hint (ops.chip_share; tests), i.e. equal up to the fp32 summation order of split-K.  A clip's `seconds` is then its share of the rank's wall clock (its own in-flight time, scaled so
     that the clips of a rank add up to the rank's wall clock), which keeps `summarize` and the cost-model fit meaningful."""
     parts = shard.assign_sequences([shard.clip_cost(s.frames - 1, s.objects) for s in specs], world)
     if lanes <= 1:

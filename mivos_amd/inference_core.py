@@ -274,6 +274,7 @@ class InferenceCore:
     # over disjoint frame ranges that only READ the certain memory): with everything resident in HBM they advance in turn, frame
     # by frame, on two HIP streams.  Same kernels, same inputs, same results; MIVOS_CONCURRENT_PASSES=0 runs them one after the other.
     CONCURRENT_PASSES = os.environ.get("MIVOS_CONCURRENT_PASSES", "1") != "0"
+    PASS_CHIP_SHARE = 2     # what the convolutions are told while the two passes are in flight (mivos_conv_desc.chip_share: launch geometry)
 
     def _run_passes(self, rows, key_v, idx, step_cb=None):
         nc = self._certain_k.shape[1]
@@ -295,7 +296,7 @@ class InferenceCore:
                  (side, self._pass_steps(plans[1], rows, key_v, idx, step_cb=step_cb))]
         for t in (rows, key_v):
             t.record_stream(side)
-        with ops.chip_share(2 * ops.CHIP_SHARE):
+        with ops.chip_share(self.PASS_CHIP_SHARE * ops.CHIP_SHARE):
             while lanes:
                 for lane in list(lanes):
                     with torch.cuda.stream(lane[0]):

@@ -264,7 +264,7 @@ import collections
 _act_scratch = collections.OrderedDict()
 ACT_SCRATCH_ENTRIES = 256   # scratch buffers kept per process (least recently used ones go first)
 CHIP_SHARE = 1          # independent launch streams the caller keeps busy on this GPU (lanes of run_suite / bench, the two passes of an interaction):
-                        # passed to every convolution as mivos_conv_desc.chip_share (launch-geometry hint; results do not depend on it)
+                        # passed to every convolution as mivos_conv_desc.chip_share (launch-geometry hint: split-K slicing, i.e. results equal up to the fp32 summation order)
 COUT1_PROJECTION = True # one-output-channel 3x3 layers as a 1x1 projection to nine tap products + tap_sum9 (False: the generic kernels; diagnostics)
 USE_ACT_PATH = True     # run conv -> conv edges on the LDS-DMA kernels (needs CONV_PRECISION == "f16x3")
 

@@ -40,7 +40,7 @@ def main():
     torch.set_grad_enabled(False)
     cfg = G.SESSION
     ref, prop, fuse = ref_loader.build_reference_networks(top_k=cfg["top_k"])
-    sd, fsd = Wt.make_prop_state(0), Wt.make_fuse_state(0)
+    sd, fsd = G.session_states()
     prop.load_state_dict(sd)
     fuse.load_state_dict(fsd)
     images, gt = O.synthetic_clip(cfg["t"], cfg["h"], cfg["w"], cfg["k"], cfg["seed"])
@@ -54,6 +54,14 @@ def main():
         same = np.array_equal(out[k], oout[k])
         if not same:
             print("oracle differs from the reference on", k)
+    # admission of the fixture: the reference's arithmetic in fp64 (oracle, bit-identical to the reference in fp32) against its fp32 run
+    from mivos_amd.util.tensor_util import compute_np_iou
+    o64 = O.OracleCore(sd, fsd, images, cfg["k"], mem_freq=cfg["mem_freq"], top_k=cfg["top_k"], dtype=torch.float64)
+    g64, _ = G.scripted_session(o64, gt)
+    self_iou = [float(np.mean([compute_np_iou(a == j, b == j) for j in range(1, cfg["k"] + 1)])) for (_, a), (_, b) in zip(g.events, g64.events)]
+    out["self_iou_fp32_vs_fp64"] = np.asarray(self_iou)
+    print("reference fp32 vs fp64 IoU per event:", " ".join(f"{x:.5f}" for x in self_iou))
+    assert min(self_iou) >= 0.9995, "fixture not well conditioned"
     print("events:", [n for n, _ in g.events])
     print("progress:", out["progress"].tolist())
     path = os.path.join(ROOT, "tests", "golden", "gui_small.npz")
