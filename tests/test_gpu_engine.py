@@ -44,7 +44,10 @@ def mean_iou(a, b, k):
     return float(np.mean([compute_np_iou(a == j, b == j) for j in range(1, k + 1)]))
 
 
-ARBITRATION_FACTOR, ARBITRATION_FLOOR = 2.0, 2.5e-4
+# Round 5: factor 2.0 -> 1.5.  On a well-conditioned session the engine sits at 1.06 - 1.14 x the reference's own distance from fp64 (medians over the
+# 137 frames of the long config-3 session, profiles/r05d_long_session_parity_conditioned_fixture.json; the exact-fp32 mode 1.08 - 1.18), and of the 83 frames
+# in the committed records of the whole suite (profiles/r04g_parity_ratios.jsonl) all but the K = 1 session's two documented tie frames keep >= 50 % slack at 1.5.
+ARBITRATION_FACTOR, ARBITRATION_FLOOR = 1.5, 2.5e-4
 TIE_MARGIN, TIE_QUANTILE, TIE_CAP = 1e-3, 1e-4, 5e-2
 # FROZEN (round 4): the tie clause's quantile is the documented 1e-4.  A test that needs more passes its own
 # `tie_quantile` with the justification written at the call site; every record names the clause each frame passed through and
@@ -56,7 +59,7 @@ def fp64_gate(tag, eng_prob, ref32_prob, ref64_prob, margins=None, tie_quantile=
     """The closed-loop parity gate, fp64-arbitrated.  Per frame f, with e = |engine - fp64| and r = |reference_fp32 -
     fp64| (the reference's OWN fp32 arithmetic against an fp64 run of the same algorithm):
 
-      strict clause   max e_f <= 2 max r_f + 2.5e-4        (2.5e-4 = the probability equivalent of the north star's 1e-3 logit bar)
+      strict clause   max e_f <= 1.5 max r_f + 2.5e-4       (2.5e-4 = the probability equivalent of the north star's 1e-3 logit bar)
 
     The algorithm is discontinuous: a memory position whose rank-k / rank-(k+1) affinities are closer than the fp32 rounding noise of
     the keys (55 convolutions deep: 1e-4 ... 3e-4 on keys of magnitude 10 for the reference's fp32 run and for the engine alike, i.e.
