@@ -16,7 +16,12 @@
  *         base + n*nstride + (y*W + x)*pstride + c        (strides in ELEMENTS)
  *     so channel slices / concatenations / memory-bank slots are expressed with strides, not copies;
  *   - single-channel maps (masks, probabilities, logits) are planar [planes][H*W].
- * Re-entrancy: functions keep no global state besides the thread-local error string.
+ * Re-entrancy: calls are safe from any thread / on any stream; no result depends on library state.  What the library keeps
+ * between calls, all of it process-wide and none of it data: the thread-local error string; tuning knobs read once from the
+ * environment (MIVOS_PP_*, MIVOS_MEMREAD_*: launch geometry only) and the three mivos_memory_read_set_* thresholds; a per-device
+ * record of which kernels had their dynamic-LDS attribute raised; and a small mutex-guarded map (<= 256 entries) from a memory-read
+ * workspace pointer to the query-tile size its last select launch used, which mivos_memory_read_finalize* checks against the plan
+ * that launch left in the workspace header.
  */
 #ifndef MIVOS_HIP_H_
 #define MIVOS_HIP_H_

@@ -217,8 +217,9 @@ def make_s2m_state(seed=0, calib="golden"):
 # (the reference's aggregate_wbg turns fp32 sigmoids back into logits, which loses everything once 1 - p approaches the fp32 spacing:
 # at LOGIT_STD = 1.5 with the untrained decoder's mean logit of +3.8 the tails reach |z| > 12 and the reference's OWN fp32 and fp64 runs
 # differ by 1e-3 in probability) and a weaker mask feedback (errors stop accumulating from frame to frame).  Measured on the 70-frame
-# config-3 clip: reference fp32 vs fp64 IoU 0.9997 stationary instead of 0.995 (scripts/studies/fixture_conditioning.py, docs/NOTEBOOK.md).
-CLOSED_LOOP_CONDITIONING = dict(logit_gain=0.6, mask_gain=0.3)
+# config-3 clip: reference fp32 vs fp64 IoU >= 0.9995 at all 137 steps of the session (mean 0.9997) instead of 0.927 ... 0.995
+# (scripts/studies/fixture_conditioning.py, scripts/long_session_parity.py, docs/NOTEBOOK.md).
+CLOSED_LOOP_CONDITIONING = dict(logit_gain=0.6, mask_gain=0.2)
 
 
 def condition_state(sd, key_gain=1.0, logit_gain=1.0, mask_gain=1.0, logit_bias=0.0, resid_gain=1.0):

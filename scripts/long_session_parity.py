@@ -29,8 +29,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 CFG = dict(frames=70, height=480, width=854, objects=5, top_k=50, mem_freq=5, seed=100, interactions=[0, 69],
-           # conditioning of the fixture (synthetic.condition_state / synthetic_clip(texture=...)); all 1 / 0 = the round-4 fixture
-           key_gain=1.0, logit_gain=1.0, mask_gain=1.0, logit_bias=0.0, fuse_logit_gain=1.0, texture=0.0, clip_frames=None)
+           # conditioning of the fixture (synthetic.condition_state / synthetic_clip(texture=...)).  Round 5: logit gain 0.6, mask gain 0.2 - admitted because
+           # the reference's own fp32 and fp64 runs agree to IoU >= 0.9995 at every one of the 137 steps on it (all gains 1 = the round-4 fixture: 0.927)
+           key_gain=1.0, logit_gain=0.6, mask_gain=0.2, logit_bias=0.0, fuse_logit_gain=1.0, texture=0.0, clip_frames=None)
 
 
 def clip(cfg):
