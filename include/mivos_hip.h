@@ -296,6 +296,12 @@ int64_t mivos_memory_read_set_q256_min(int64_t n_mem_min);
  * (largest key norm of the object x the query's norm x 1.25 x 2^-10) cannot rule a candidate out.  Same selection, a third of the
  * matrix work for almost every tile.  Returns the previous setting; negative = only query. */
 int mivos_memory_read_set_hifirst(int on);
+/* Launch geometry of the persistent select kernels: at most n_wg workgroups (0 = one per CU, the default).  A select workgroup holds
+ * 155 KB of LDS, so with one per CU nothing else runs while the launch lasts; a caller that keeps several launch streams busy on the GPU
+ * (several clips in flight) sets CUs / streams and the launches of the other streams run beside it (+3.4 % frames/s with two 480p
+ * sessions in flight, profiles/r05e_select_workgroups_ab.txt).  The candidate lists follow the work partition; results are identical.
+ * Returns the previous value; negative = only query. */
+int mivos_memory_read_set_workgroups(int n_wg);
 int mivos_memory_read_select(const float *keys, int64_t keys_ostride, const float *qk, int n_obj,
                              int64_t n_mem, int n_q, int top_k, void *workspace, int64_t workspace_bytes,
                              void *stream);

@@ -80,6 +80,7 @@ PROTOTYPES = {
     "mivos_memory_read_set_q128_min": (i64, [i64]),
     "mivos_memory_read_set_q256_min": (i64, [i64]),
     "mivos_memory_read_set_hifirst": (C.c_int, [C.c_int]),
+    "mivos_memory_read_set_workgroups": (C.c_int, [C.c_int]),
     "mivos_memory_read_dense_workspace_bytes": (i64, [C.c_int, i64, C.c_int]),
     "mivos_memory_read_dense": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, i64, i64, i64, C.c_int, C.c_int, i64, C.c_int, vp, i64, vp]),
     "mivos_memory_read_topk_any_workspace_bytes": (i64, [C.c_int, i64, C.c_int]),

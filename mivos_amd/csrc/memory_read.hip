@@ -1421,6 +1421,11 @@ static int compute_units() {
   return c;
 }
 
+// Workgroups of the persistent select kernels: 0 = one per CU (the kernel then owns the chip for its whole duration: 155 KB of LDS per
+// workgroup leave no room for anybody else's); n > 0 = at most n - set by callers that keep several launch streams busy on the GPU
+// (mivos_memory_read_set_workgroups; ops.chip_share sets CUs / streams), so that another clip's kernels run beside a select launch.
+static std::atomic<int> g_select_wgs{0};
+
 static Plan make_plan(int n_obj, long long n_mem, int n_q, int top_k, int qt) {
   Plan p;
   p.qt = qt;
@@ -1428,8 +1433,9 @@ static Plan make_plan(int n_obj, long long n_mem, int n_q, int top_k, int qt) {
   p.streams = n_obj * p.n_qtiles;
   p.tps = cdiv(n_mem, KT);
   p.total = (long long)p.streams * p.tps;
-  static const int forced = getenv("MIVOS_MEMREAD_WGS") ? atoi(getenv("MIVOS_MEMREAD_WGS")) : 0;   // tuning only
-  long long n_wg = forced > 0 ? forced : compute_units();
+  static const int forced_env = getenv("MIVOS_MEMREAD_WGS") ? atoi(getenv("MIVOS_MEMREAD_WGS")) : 0;   // tuning only
+  const int forced = g_select_wgs.load(std::memory_order_relaxed) > 0 ? g_select_wgs.load(std::memory_order_relaxed) : forced_env;
+  long long n_wg = forced > 0 ? (forced < compute_units() ? forced : compute_units()) : compute_units();
   // a stream is cut into at most MAX_SLOTS segments: ceil(tps / tiles_per_wg) + 1 <= MAX_SLOTS
   if (n_wg > (long long)p.streams * (MAX_SLOTS - 2)) n_wg = (long long)p.streams * (MAX_SLOTS - 2);
   if (n_wg > p.total) n_wg = p.total;
@@ -1595,6 +1601,12 @@ using namespace mivos;
 extern "C" int64_t mivos_memory_read_workspace_bytes(int n_obj, int64_t n_mem, int n_q, int top_k) {
   if (n_obj < 1 || n_q < 1 || n_mem < 1 || top_k < 1) return 0;
   return HEADER_BYTES + max_lists_bytes(n_obj, n_mem, n_q, top_k) + cand3_bytes() + kmax_bytes(n_obj);
+}
+
+extern "C" int mivos_memory_read_set_workgroups(int n_wg) {
+  const int prev = g_select_wgs.load(std::memory_order_relaxed);
+  if (n_wg >= 0) g_select_wgs.store(n_wg, std::memory_order_relaxed);
+  return prev;
 }
 
 extern "C" int mivos_memory_read_set_hifirst(int on) {

@@ -76,10 +76,17 @@ def chip_share(n):
     """Inside: convolutions are told that `n` independent launch streams share this GPU (CHIP_SHARE -> mivos_conv_desc.chip_share)."""
     global CHIP_SHARE
     old, CHIP_SHARE = CHIP_SHARE, max(1, int(n))
+    lib, old_wgs = None, 0
+    if torch.cuda.is_available():           # the persistent select kernels give the other streams their share of the CUs
+        lib = _lib.load()
+        cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        old_wgs = lib.mivos_memory_read_set_workgroups(cus // CHIP_SHARE if CHIP_SHARE > 1 else 0)
     try:
         yield
     finally:
         CHIP_SHARE = old
+        if lib is not None:
+            lib.mivos_memory_read_set_workgroups(old_wgs)
 
 
 def publish_constants():

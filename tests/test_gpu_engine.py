@@ -45,7 +45,7 @@ def mean_iou(a, b, k):
 
 
 # Round 5: factor 2.0 -> 1.5.  On a well-conditioned session the engine sits at 1.06 - 1.14 x the reference's own distance from fp64 (medians over the
-# 137 frames of the long config-3 session, profiles/r05d_long_session_parity_conditioned_fixture.json; the exact-fp32 mode 1.08 - 1.18), and of the 83 frames
+# 137 frames of the long config-3 session, profiles/r05e_long_session_parity.json; the exact-fp32 mode 1.08 - 1.18), and of the 83 frames
 # in the committed records of the whole suite (profiles/r04g_parity_ratios.jsonl) all but the K = 1 session's two documented tie frames keep >= 50 % slack at 1.5.
 ARBITRATION_FACTOR, ARBITRATION_FLOOR = 1.5, 2.5e-4
 TIE_MARGIN, TIE_QUANTILE, TIE_CAP = 1e-3, 1e-4, 5e-2
