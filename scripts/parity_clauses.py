@@ -8,7 +8,7 @@ import json
 import sys
 
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip()]
-print(f"{len(rows)} gate records; strict clause: |engine - fp64| <= 2 |reference_fp32 - fp64| + 2.5e-4 per frame")
+print(f"{len(rows)} gate records; strict clause: |engine - fp64| <= 1.5 |reference_fp32 - fp64| + 2.5e-4 per frame (factor 2 until round 4)")
 tie = 0
 for r in rows:
     cl = r.get("clauses") or []
