@@ -104,6 +104,10 @@ typedef struct {
                           count on 1/n of the workgroup slots (a second clip's launches fill the rest; splitting K to fill them
                           would only add partial-sum traffic).  Results are the same up to the fp32 summation order a different
                           number of K slices implies (rounding level, like a different batch size).                            */
+  uint32_t *status;    /* optional device word (4-byte aligned, zeroed by the caller; NULL: off).  Precision 1 / 2 only: the
+                          epilogue ORs bit 0 into it when an output value leaves the fp16 range (|y| > 65504) - such a value
+                          becomes inf in the hi half of the next layer's operand split, and the ReLUs / clamps downstream would
+                          hide the NaNs that follow.  One atomic per offending workgroup; nothing is written otherwise.         */
 } mivos_conv_desc;
 
 int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream);

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmivos_hip.so")
+LIB_PATH = os.environ.get("MIVOS_HIP_LIB") or os.path.join(_HERE, "libmivos_hip.so")      # (MIVOS_HIP_LIB: A/B of two builds of the library, tuning only)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
                 ("y2_nstride", i64), ("y2_pstride", i64), ("res_nstride", i64), ("res_pstride", i64),
                 ("workspace", vp), ("workspace_bytes", i64),
                 ("x_rstride", i64), ("y_rstride", i64), ("res_rstride", i64),
-                ("x_border", i32), ("x_format", i32), ("y_format", i32), ("res_format", i32), ("dilation", i32), ("chip_share", i32)]
+                ("x_border", i32), ("x_format", i32), ("y_format", i32), ("res_format", i32), ("dilation", i32), ("chip_share", i32), ("status", vp)]
 
 
 class InterleaveDesc(C.Structure):

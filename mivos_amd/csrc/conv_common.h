@@ -18,7 +18,18 @@ struct ConvP {
   int y_fmt, r_fmt;                    // 0: fp32, 1: SH32 (fp16 hi | lo lines per 32 channels, conv_f16x3_dma.hip)
   int dil;                             // tap spacing (atrous convolution), >= 1
   int share;                           // launch streams the caller keeps busy on this GPU (>= 1): geometry hint, never changes results
+  unsigned *status;                    // optional device word: bit 0 is set when an output of an f16x3 launch leaves the fp16 range (|y| > 65504)
 };
+
+// fp16-range guard of the f16x3 paths (precision 1 / 2): an output beyond 65504 becomes inf in the hi half of the NEXT layer's operand split, and the
+// ReLUs / clamps downstream turn the resulting NaNs into finite numbers - silently.  The epilogues keep a running maximum of what they store and
+// raise bit 0 of *p.status (mivos_conv_desc.status) for the host to find (ops.check_activation_range, once per interaction).
+__device__ __forceinline__ float range_max(float amax, f32x4 v) {
+  return fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+__device__ __forceinline__ void range_flag(const ConvP &p, float amax) {
+  if (p.status && amax > 65504.f) atomicOr(p.status, 1u);
+}
 
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 
@@ -62,6 +73,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // acc tile layout (32x32 MFMA C/D): lane (n = lane&31, h = lane>>5), register r -> pixel row mfma32_row(r, lane).
 template <int MT, int NT>
 __device__ __forceinline__ void epilogue_scalar(const f32x16 (&acc)[MT][NT], const ConvP &p, int m_base, int n_base, int lane) {
+  float amax = 0.f;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n_base + j * 32 + (lane & 31);
@@ -84,10 +96,12 @@ __device__ __forceinline__ void epilogue_scalar(const f32x16 (&acc)[MT][NT], con
         float v = acc[i][j][r] * sc + bi;
         if (p.res) v += p.res[(long long)img * p.r_ns + (long long)oh * p.r_rs + (long long)ow * p.r_ps + n];
         if (p.relu_out) v = fmaxf(v, 0.f);
+        amax = fmaxf(amax, fabsf(v));
         dst[(long long)img * d_ns + (long long)oh * d_rs + (long long)ow * d_ps + dn] = v;
       }
     }
   }
+  range_flag(p, amax);
 }
 
 // Vectorised epilogue: each 32x32 tile is transposed through a per-wave LDS scratch (32 x 36 floats) so
@@ -100,6 +114,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float 
                                              int n_base, int lane) {
   constexpr bool PREFETCH = MT <= 2;       // 256x256 tiles (128 accumulator VGPRs) have no registers to spare for it
   const int prow0 = lane >> 3, c4 = (lane & 7) * 4;
+  float amax = 0.f;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n_base + j * 32 + c4;
@@ -153,6 +168,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float 
             }
             v.x += rr[ii][ps].x; v.y += rr[ii][ps].y; v.z += rr[ii][ps].z; v.w += rr[ii][ps].w;
             if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            amax = range_max(amax, v);
             if (d_fmt) store_sh32x4(dst, yo[ii][ps], dn, v);
             else *reinterpret_cast<f32x4 *>(dst + yo[ii][ps] + dn) = v;
           }
@@ -160,6 +176,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float 
       }
     }
   }
+  range_flag(p, amax);
 }
 
 // SH32-output epilogue (y_fmt == 1, single destination): a lane owns 8 consecutive channels of one pixel, so the fp16 hi
@@ -170,6 +187,7 @@ template <int MT, int NT, int IB = (MT > 2 ? 1 : MT)>
 __device__ __forceinline__ void epilogue_sh32(const f32x16 (&acc)[MT][NT], float *scratch, const ConvP &p, int m_base, int n_base, int lane) {
   constexpr bool PREFETCH = MT <= 2;
   const int prow0 = lane >> 2, c8 = (lane & 3) * 8;
+  float amax = 0.f;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n_base + j * 32 + c8;
@@ -230,6 +248,7 @@ __device__ __forceinline__ void epilogue_sh32(const f32x16 (&acc)[MT][NT], float
               float t = v[q] * sc[q] + bi[q];
               t += rr[ii][ps][q];
               t = p.relu_out ? fmaxf(t, 0.f) : t;
+              amax = fmaxf(amax, fabsf(t));
               hi[q] = (_Float16)t;
               lo[q] = (_Float16)(t - (float)hi[q]);
             }
@@ -241,6 +260,7 @@ __device__ __forceinline__ void epilogue_sh32(const f32x16 (&acc)[MT][NT], float
       }
     }
   }
+  range_flag(p, amax);
 }
 
 // split-K: output element group (pixel m, channels n..n+3) = act(sum_s partial[s] * scale + bias + res), slices summed in
@@ -263,6 +283,7 @@ __device__ __forceinline__ void splitk_finish4(const ConvP &p, int n_slices, int
     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
   }
   if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  range_flag(p, range_max(0.f, v));
   float *dst;
   long long d_ns, d_rs, d_ps;
   int dn, d_fmt;

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvP p, int kpad4) 
   if (p.kt_split) {     // raw fp32 partial tile of this K slice: [slice][M][Cout], dense
     ConvP q = p;
     q.scale = q.bias = q.res = nullptr;
+    q.status = nullptr;                    // partial sums are not outputs: the reduce kernel checks the finished values
     q.relu_out = 0;
     q.split = p.Cout;
     q.y = p.partial + (long long)blockIdx.y * p.M * p.Cout;

@@ -235,6 +235,7 @@ int conv_params_from_desc(const mivos_conv_desc *d, ConvP &p) {
   p.r_rs = d->res_rstride ? d->res_rstride : (long long)d->Wo * d->res_pstride;
   p.x_border = d->x_border; p.y_fmt = d->y_format; p.r_fmt = d->res_format;
   p.share = d->chip_share > 1 ? (d->chip_share > 8 ? 8 : d->chip_share) : 1;
+  p.status = d->precision != 0 ? d->status : nullptr;          // exact fp32 has no fp16 range to leave
   if ((d->x_format != 0) != (d->precision == 2)) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: x_format 1 (SH32) goes with precision 2 and only with it");
   if (d->precision != 2 && p.x_rs != (long long)d->W * d->x_pstride) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d: precision 0/1 read dense input rows");
   if (d->precision != 2 && (p.y_rs != (long long)d->Wo * d->y_pstride || (d->res && p.r_rs != (long long)d->Wo * d->res_pstride)))

@@ -401,8 +401,12 @@ class InferenceCore:
         # (Rounds 2-3 probed the probabilities for NaN here.  That probe could never fire: an activation beyond the fp16 range of the
         # f16x3 operands becomes inf / NaN inside a convolution, but every ReLU (fmaxf) on the way - each bottleneck's output, the
         # decoder's `pred` input - and the clamp of aggregate_wbg return finite numbers for NaN, so the corruption is silent by the
-        # time it reaches `prob`.  The guard that exists is the input check of __init__; INTEGRATION.md "Limits" says so.)
-        return self._argmax_and_copy(l, r, t, b, P)
+        # time it reaches `prob`.  The guards that exist: the input check of __init__ and, since round 5, the convolution epilogues' range
+        # flag read below.)
+        out = self._argmax_and_copy(l, r, t, b, P)
+        if ops.CONV_PRECISION == "f16x3":          # the epilogues' fp16-range guard (round 5): an overflow INSIDE the network is no longer silent
+            ops.check_activation_range(self.device)
+        return out
 
     def _argmax_and_copy(self, l, r, t, b, P):
         if self.prob.device == self.device:

@@ -411,7 +411,8 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
             rn, rp = _nhwc_strides(res)
         d.res_nstride, d.res_pstride = (0 if (res.shape[0] == 1 and n > 1) else rn), rp
     ws = _workspace(SPLITK_WORKSPACE_BYTES, dev)
-    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() - STATUS_BYTES
+    d.status = ws.data_ptr() + ws.numel() - STATUS_BYTES          # fp16-range guard of the f16x3 epilogues (check_activation_range)
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -471,7 +472,7 @@ def fusion_net_forward(x16, layers, final, planes=None, shape=None):
         d.x16, d.planes = _f32(x16).data_ptr(), None
     d.logits, d.scratch, d.scratch_floats = out.data_ptr(), scratch.data_ptr(), n
     d.batch, d.height, d.width = b, h, w
-    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() - STATUS_BYTES      # (the tail of the split-K workspace is the status block)
     check(lib.mivos_fusion_net_forward(C.byref(d), _stream()))
     return out
 
@@ -641,13 +642,38 @@ def upsample2x_add(skip, up):
 _ws_cache = {}
 
 
+STATUS_BYTES = 64       # tail of every split-K workspace: status words the kernels raise (word 0 bit 0: an f16x3 output left the fp16 range)
+
+
 def _workspace(nbytes, device, purpose="splitk"):
     key = (purpose, device.index, torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        ws[-STATUS_BYTES:].zero_()
         _ws_cache[key] = ws
     return ws
+
+
+def check_activation_range(device):
+    """Raise MivosHipError if any f16x3 convolution launched on `device` since the last check produced an output beyond the fp16 range
+    (|y| > 65504: the next layer's hi / lo operand split would turn it into inf, and the ReLUs / `aggregate_wbg`'s clamp downstream would
+    turn the NaNs that follow into finite numbers - silently).  The epilogues raise a status word in the tail of their stream's split-K
+    workspace (mivos_conv_desc.status); this reads those words (one 4-byte copy per stream that launched convolutions) and clears them.
+    InferenceCore calls it once per interaction, next to the mask download it waits for anyway.  Covers the convolution epilogues (trunks,
+    KeyValue, decoder) - the stems, FusionNet's own kernels and the pointwise kernels are not instrumented (INTEGRATION.md "Limits")."""
+    device = torch.device(device)
+    bad = False
+    for (purpose, index, _stream_id), ws in list(_ws_cache.items()):
+        if purpose != "splitk" or index != device.index:
+            continue
+        word = ws[-STATUS_BYTES:-STATUS_BYTES + 4].view(torch.int32)
+        if int(word.item()) != 0:
+            bad = True
+            word.zero_()
+    if bad:
+        raise MivosHipError("an activation left the fp16 range (|y| > 65504) inside an f16x3 convolution: the default precision carries operands as fp16 hi + lo "
+                            "pairs (INTEGRATION.md 'Limits').  Results of this interaction are invalid; use ops.CONV_PRECISION = 'f32' for these weights.")
 
 
 def _rows(t, width):

@@ -601,8 +601,7 @@ def test_no_topk_network_closed_loop_vs_oracle(synthetic_states):
 def test_fp16_range_overflow_is_detected(synthetic_states):
     """The f16x3 operands are fp16 hi + lo pairs: values beyond +-65504 become inf (INTEGRATION.md "Limits").  A clip whose frames are
     1e6 times brighter than anything an image normalisation produces must raise instead of returning garbage masks; the exact-fp32
-    mode runs the same clip.  (The check is on the INPUT: an overflow that arises inside the network is silent - ReLUs and the clamp
-    of aggregate_wbg turn NaN into finite numbers - and INTEGRATION.md says so.)"""
+    mode runs the same clip.  (This check is on the INPUT; overflows arising inside the network: the next test.)"""
     from mivos_amd import ops
     sd, fsd = synthetic_states
     prop, fuse = PropagationNetwork(top_k=20), FusionNet()
@@ -620,6 +619,34 @@ def test_fp16_range_overflow_is_detected(synthetic_states):
     finally:
         ops.CONV_PRECISION = old
     assert out.shape == (3, 128, 160)
+
+
+def test_fp16_range_overflow_inside_the_network_is_detected(synthetic_states):
+    """Round 5: an overflow that arises INSIDE the network (frames fine, a layer's output beyond 65504) is no longer silent - the convolution
+    epilogues raise a status word (mivos_conv_desc.status) and InferenceCore reads it once per interaction (ops.check_activation_range).  Weights
+    whose decoder blows up: a 3x3 layer of the decoder scaled by 1e6.  The exact-fp32 mode runs the same weights; afterwards the flag is clear and
+    the ordinary weights run as before."""
+    from mivos_amd import ops
+    sd, fsd = synthetic_states
+    images, gt = O.synthetic_clip(3, 128, 160, 1, seed=50)
+    wild = dict(sd)
+    wild["decoder.up_16_8.out_conv.conv1.weight"] = sd["decoder.up_16_8.out_conv.conv1.weight"] * 1e6
+    prop, fuse = PropagationNetwork(top_k=20), FusionNet()
+    prop.load_state_dict(wild)
+    fuse.load_state_dict(fsd)
+    prop, fuse = prop.to(DEV).eval(), fuse.to(DEV).eval()
+    with pytest.raises(ops.MivosHipError, match="left the fp16 range"):
+        InferenceCore(prop, fuse, images, 1, device=DEV).interact(gt[0], 0)
+    old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f32"
+    try:
+        out = InferenceCore(prop, fuse, images, 1, device=DEV).interact(gt[0], 0)
+    finally:
+        ops.CONV_PRECISION = old
+    assert out.shape == (3, 128, 160)
+    ops.check_activation_range(torch.device(DEV))                    # the raise cleared the flag
+    prop.load_state_dict(sd)
+    prop = prop.to(DEV).eval()
+    assert InferenceCore(prop, fuse, images, 1, device=DEV).interact(gt[0], 0).shape == (3, 128, 160)
 
 
 def test_topk_larger_than_memory_raises_like_reference(nets):
