@@ -439,7 +439,7 @@ def test_480p_single_step_logits_vs_oracle(nets, synthetic_states, K):
 def test_480p_propagation_vs_oracle(nets, synthetic_states, K):
     """Closed loop at 480p, top_k = 20 (config 2's setting): 3 propagated frames, then a second interaction that fuses the
     frames in between.  Masks IoU >= 0.999; probabilities gated like the headline test below: per frame the engine may be at
-    most twice as far from an fp64 run of the oracle as the fp32 oracle itself, plus the 1e-3-logit equivalent."""
+    most 1.5 times as far from an fp64 run of the oracle as the fp32 oracle itself, plus the 1e-3-logit equivalent."""
     prop, fuse = nets
     sd, fsd = synthetic_states
     images, gt = O.synthetic_clip(4, 480, 854, K, seed=20 + K)
@@ -465,9 +465,8 @@ def test_headline_config_parity_with_fp64_arbitration(synthetic_states, K, top_k
     interact(last) so that every frame in between is fused (K=5 is BASELINE config 3).  Masks: IoU >= 0.999 vs the fp32
     oracle.  Probabilities: the algorithm is closed-loop, so any two fp32 implementations drift apart over fed-back
     frames; the gate is that the engine stays as close to an fp64 run of the oracle as the fp32 oracle itself does,
-    per frame: |engine - fp64| <= 2 |oracle_fp32 - fp64| + 2.5e-4.  (Both are maxima of rounding noise over 4e5 pixels: a factor
-    of two between two such maxima is not significant - measured 1.97 on a frame where both are ~3e-4 - and 2.5e-4 is the
-    probability equivalent of the 1e-3 logit bar; a drift to 2e-3 fails unless the reference's own fp32 drifts as far.)"""
+    per frame: |engine - fp64| <= 1.5 |oracle_fp32 - fp64| + 2.5e-4 (ARBITRATION_FACTOR; 2 until round 4).  (Both are maxima of rounding noise over 4e5 pixels; where both are tiny - ~3e-4, ratios up to 2 occur - the floor of 2.5e-4, the
+    probability equivalent of the 1e-3 logit bar, decides; a drift to 2e-3 fails unless the reference's own fp32 drifts as far.)"""
     sd, fsd = synthetic_states
     prop, fuse = PropagationNetwork(top_k=top_k), FusionNet()
     prop.load_state_dict(sd)
