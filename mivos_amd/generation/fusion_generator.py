@@ -11,6 +11,8 @@ WITHOUT fusion and return the soft probabilities of every frame.  Same construct
     14-fold redundancy;
   * missing frames of a pass are encoded a batch at a time like InferenceCore does.
 """
+import os
+
 import torch
 
 from .. import ops
@@ -38,6 +40,7 @@ class FusionGenerator:
         self.kh, self.kw = self.nh // 16, self.nw // 16
         self.query_buf = {}
         self.propagated_frames = 0
+        self._pass_stream = None
 
     def reset(self, k):
         self.k = k
@@ -62,8 +65,9 @@ class FusionGenerator:
         with ops.on_device(self.device):
             return self._query(idx).as_reference_tuple()
 
-    def do_pass(self, key_k, key_v, idx, left_limit, right_limit, forward=True):
-        """key_k / key_v: keys / values of the annotated frame, rows layout [K,h,w,C] (or the reference's [K,C,1,h,w])."""
+    def _pass_steps(self, key_k, key_v, idx, left_limit, right_limit, forward):
+        """One pass as a generator: every `next()` enqueues one propagated frame on the current HIP stream and waits for nothing (the
+        form InferenceCore._pass_steps has; `interact_mask` advances the forward and the backward pass in turn on two streams)."""
         if key_k.dim() == 5 and key_k.shape[1] == CK:
             key_k, key_v = key_k[:, :, 0].permute(0, 2, 3, 1), key_v[:, :, 0].permute(0, 2, 3, 1)
         frames = list(range(idx + 1, right_limit + 1)) if forward else list(range(idx - 1, left_limit - 1, -1))
@@ -88,6 +92,40 @@ class FusionGenerator:
                 if ksplit is not None:
                     ops.split_keys(keys[:, st.slot], ksplit[:, st.slot])
             self.propagated_frames += 1
+            yield st.ti
+
+    def do_pass(self, key_k, key_v, idx, left_limit, right_limit, forward=True):
+        """key_k / key_v: keys / values of the annotated frame, rows layout [K,h,w,C] (or the reference's [K,C,1,h,w])."""
+        for _ in self._pass_steps(key_k, key_v, idx, left_limit, right_limit, forward):
+            pass
+
+    # the two passes from a reference frame are independent (fusion_generator.py:97-98: two do_pass calls over disjoint frames): they advance in
+    # turn on two HIP streams, like the two passes of InferenceCore.interact (MIVOS_CONCURRENT_PASSES=0: one after the other)
+    CONCURRENT_PASSES = os.environ.get("MIVOS_CONCURRENT_PASSES", "1") != "0"
+    PASS_CHIP_SHARE = 2
+
+    def _run_passes(self, key_k, key_v, idx, left_limit, right_limit):
+        both = idx < right_limit and idx > left_limit
+        if not (both and self.CONCURRENT_PASSES):
+            self.do_pass(key_k, key_v, idx, left_limit, right_limit, True)
+            self.do_pass(key_k, key_v, idx, left_limit, right_limit, False)
+            return
+        main = torch.cuda.current_stream()
+        if self._pass_stream is None:
+            self._pass_stream = torch.cuda.Stream(device=self.device)
+        side = self._pass_stream
+        side.wait_stream(main)
+        for t in (key_k, key_v):
+            t.record_stream(side)
+        lanes = [(main, self._pass_steps(key_k, key_v, idx, left_limit, right_limit, True)),
+                 (side, self._pass_steps(key_k, key_v, idx, left_limit, right_limit, False))]
+        with ops.chip_share(self.PASS_CHIP_SHARE * ops.CHIP_SHARE):
+            while lanes:
+                for lane in list(lanes):
+                    with torch.cuda.stream(lane[0]):
+                        if next(lane[1], None) is None:
+                            lanes.remove(lane)
+        main.wait_stream(side)
 
     def interact_mask(self, mask, idx, left_limit, right_limit):
         """mask [K,1,H,W]: the objects' masks of frame idx (generate_fusion.py:104) -> probabilities [K+1, T, H, W] of the frames
@@ -98,7 +136,6 @@ class FusionGenerator:
             mask = aggregate_wbg(mask.contiguous(), keep_bg=True)
             self.prob[:, idx] = mask
             key_k, key_v = self.prop_net.memorize_into(self.get_im(idx), mask[1:])
-            self.do_pass(key_k, key_v, idx, left_limit, right_limit, True)
-            self.do_pass(key_k, key_v, idx, left_limit, right_limit, False)
+            self._run_passes(key_k, key_v, idx, left_limit, right_limit)
             l, r, t, b = self.pad
             return self.prob[:, :, 0, t:self.nh - b, l:self.nw - r]

@@ -312,6 +312,18 @@ def test_fusion_generator_golden(nets, golden_dir, synthetic_states):
         if left > 0:
             assert float(out[:, :left].abs().max()) == 0.0                   # frames outside the range keep reset()'s zeros
     assert gen.propagated_frames == 5 + 4 and len(gen.query_buf) == 6        # 6 frames encoded ONCE for both reference frames
+    # the two passes from a reference frame advance in turn on two HIP streams (round 5): bit for bit the one-after-the-other order when both
+    # run with the same launch geometry (PASS_CHIP_SHARE = 1 here)
+    runs = {}
+    for conc in (False, True):
+        g2 = FusionGenerator(prop, images.to(DEV), c["mem_freq"])
+        g2.CONCURRENT_PASSES, g2.PASS_CHIP_SHARE = conc, 1
+        outs = []
+        for idx, left, right in c["calls"]:
+            g2.reset(c["k"])
+            outs.append(g2.interact_mask(gt[idx, 1:].to(DEV), idx, left, right).clone())
+        runs[conc] = outs
+    assert all(torch.equal(a, b) for a, b in zip(runs[False], runs[True]))
 
 
 def test_end_to_end_golden(nets, golden_dir, synthetic_states):
