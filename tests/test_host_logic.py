@@ -527,3 +527,42 @@ def test_xcd_contiguous_dealing_model():
                 assert mine == list(range(mine[0], mine[0] + len(mine))), (n, x)           # one contiguous run per XCD
             starts = [min(remap(b, n) for b in range(x, n, 8)) for x in range(8)]
             assert starts == sorted(starts)                                                  # XCD 0 first ... XCD 7 last
+
+
+def test_chip_share_context_nests_and_restores():
+    """ops.chip_share(n): the launch-geometry hint the lanes drivers set (mivos_conv_desc.chip_share); nests multiplicatively where a two-pass
+    interaction runs inside a two-lane suite (InferenceCore._run_passes: PASS_CHIP_SHARE * ops.CHIP_SHARE) and restores on exit, also on errors."""
+    from mivos_amd import ops
+    assert ops.CHIP_SHARE == 1
+    with ops.chip_share(3):
+        assert ops.CHIP_SHARE == 3
+        with ops.chip_share(2 * ops.CHIP_SHARE):
+            assert ops.CHIP_SHARE == 6
+        assert ops.CHIP_SHARE == 3
+        try:
+            with ops.chip_share(0):                      # clamped to 1
+                assert ops.CHIP_SHARE == 1
+                raise RuntimeError("x")
+        except RuntimeError:
+            pass
+        assert ops.CHIP_SHARE == 3
+    assert ops.CHIP_SHARE == 1
+
+
+def test_csrc_fingerprint_is_what_the_committed_pmc_records_carry():
+    """The PMC summaries bench.py quotes must have been read from THIS tree's kernels (scripts/csrc_fingerprint.py): the newest committed config-3 records carry its fingerprint."""
+    import glob
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    try:
+        from csrc_fingerprint import csrc_fingerprint
+    finally:
+        sys.path.pop(0)
+    fp = csrc_fingerprint(root)
+    assert len(fp) == 16 and fp == csrc_fingerprint(root)
+    for kind in ("pmc_traffic", "mfma_util"):
+        newest = sorted(glob.glob(os.path.join(root, "profiles", f"*config3*{kind}.json")))[-1]
+        assert json.load(open(newest)).get("_meta", {}).get("csrc_fingerprint") == fp, (newest, fp)
