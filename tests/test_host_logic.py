@@ -549,9 +549,11 @@ def test_chip_share_context_nests_and_restores():
     assert ops.CHIP_SHARE == 1
 
 
-def test_csrc_fingerprint_is_what_the_committed_pmc_records_carry():
-    """The PMC summaries bench.py quotes must have been read from THIS tree's kernels (scripts/csrc_fingerprint.py): the newest committed config-3 records carry its fingerprint."""
+def test_csrc_fingerprint_gates_the_committed_pmc_records():
+    """scripts/csrc_fingerprint.py is deterministic, and bench.py's lookup of the newest committed config-3 PMC record answers with numbers exactly when
+    that record carries this tree's fingerprint - with a `stale` marker otherwise (a kernel edit after the counters were read must not quote them)."""
     import glob
+    import importlib.util
     import json
     import os
     import sys
@@ -563,6 +565,10 @@ def test_csrc_fingerprint_is_what_the_committed_pmc_records_carry():
         sys.path.pop(0)
     fp = csrc_fingerprint(root)
     assert len(fp) == 16 and fp == csrc_fingerprint(root)
-    for kind in ("pmc_traffic", "mfma_util"):
-        newest = sorted(glob.glob(os.path.join(root, "profiles", f"*config3*{kind}.json")))[-1]
-        assert json.load(open(newest)).get("_meta", {}).get("csrc_fingerprint") == fp, (newest, fp)
+    spec = importlib.util.spec_from_file_location("bench_module_fp", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    newest = sorted(glob.glob(os.path.join(root, "profiles", "*config3*pmc_traffic.json")))[-1]
+    fresh = json.load(open(newest)).get("_meta", {}).get("csrc_fingerprint") == fp
+    got = bench.pmc_traffic(3, "conv_f16x3_pp_kernel<128,128,2,4,0>")
+    assert got is not None and (("bytes_per_launch" in got) if fresh else (got.get("stale") is True and "bytes_per_launch" not in got))
