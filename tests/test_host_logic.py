@@ -572,3 +572,26 @@ def test_csrc_fingerprint_gates_the_committed_pmc_records():
     fresh = json.load(open(newest)).get("_meta", {}).get("csrc_fingerprint") == fp
     got = bench.pmc_traffic(3, "conv_f16x3_pp_kernel<128,128,2,4,0>")
     assert got is not None and (("bytes_per_launch" in got) if fresh else (got.get("stale") is True and "bytes_per_launch" not in got))
+
+
+def test_condition_state_touches_only_what_it_says():
+    """synthetic.condition_state (the closed-loop fixtures' post-hoc gains): gains of 1 return the golden weights bit for bit, each knob changes exactly its tensors,
+    and synthetic_clip(texture=0) is the clip every golden vector was made with."""
+    import torch
+    from mivos_amd.util import synthetic
+    sd = synthetic.make_prop_state(0)
+    same = synthetic.condition_state(sd)
+    assert list(same) == list(sd) and all(torch.equal(same[k], sd[k]) for k in sd)
+    c = synthetic.condition_state(sd, **synthetic.CLOSED_LOOP_CONDITIONING)
+    changed = sorted(k for k in sd if not torch.equal(c[k], sd[k]))
+    assert changed == ["decoder.pred.bias", "decoder.pred.weight", "mask_rgb_encoder.conv1.weight"]
+    g, m = synthetic.CLOSED_LOOP_CONDITIONING["logit_gain"], synthetic.CLOSED_LOOP_CONDITIONING["mask_gain"]
+    assert torch.equal(c["decoder.pred.weight"], sd["decoder.pred.weight"] * g)
+    w0, w1 = sd["mask_rgb_encoder.conv1.weight"], c["mask_rgb_encoder.conv1.weight"]
+    assert torch.equal(w1[:, :3], w0[:, :3]) and torch.equal(w1[:, 3:], w0[:, 3:] * m)
+    k = synthetic.condition_state(sd, key_gain=2.0)
+    assert sorted(x for x in sd if not torch.equal(k[x], sd[x])) == ["kv_m_f16.key_proj.bias", "kv_m_f16.key_proj.weight", "kv_q_f16.key_proj.bias", "kv_q_f16.key_proj.weight"]
+    a, ga = synthetic.synthetic_clip(3, 48, 64, 2, seed=5)
+    b, gb = synthetic.synthetic_clip(3, 48, 64, 2, seed=5, texture=0.0)
+    t, _ = synthetic.synthetic_clip(3, 48, 64, 2, seed=5, texture=0.5)
+    assert torch.equal(a, b) and torch.equal(ga, gb) and not torch.equal(a, t) and t.shape == a.shape
