@@ -17,7 +17,10 @@ Workloads (fixed, `--steps/--warmup` only choose WHICH steps a
              the ranks by mivos_amd.eval_suite; strong scaling over the fixed suite (default: all 474 clips, ~3.5 min on one GPU).
 Timed region: exactly `--steps` steps after `--warmup` untimed ones, bracketed by barrier + torch.cuda.synchronize(); at
 its start every query feature that was encoded ahead of its frame's turn is dropped (`prepaid_frames: 0`).  Inputs are
-resident in HBM before the clock starts.  Multi-GPU: one process per GPU; `python bench.py --gpus N` spawns its own ranks
+resident in HBM before the clock starts.  `value` is measured with ONE session (clip) in flight per GPU - the reference's
+interactive workload; a window shorter than a session is placed across the plain / fused boundary of the session
+(window_phase).  Extra fields: `several_clips_in_flight` (--lanes sessions on as many HIP streams: suite throughput),
+`full_session`, `sustained` (>= 5 s with sampled shader clock and package power).  Multi-GPU: one process per GPU; `python bench.py --gpus N` spawns its own ranks
 through torch.distributed.run when it was not launched by it.  Configs 2/3/5: one clip per rank (weak scaling); config 4:
 the suite is split (strong scaling).  value = steps of all ranks / max-over-ranks time.
 """
@@ -60,6 +63,55 @@ CONFIGS = {
 }
 
 
+def gpu_sync(torch):
+    """torch.cuda.synchronize() where there is a GPU (the --stub-engine plumbing runs have none)."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+class StubCore:
+    """PLUMBING TEST ONLY (--stub-engine, tests/test_bench_multirank.py): the call surface of InferenceCore that this file uses (interact /
+    interact_steps with step_cb, drop_lookahead, propagated_frames) on numpy, so that the multi-rank path of configs 2 / 3 / 5 - self-spawn,
+    one clip per rank, window placement, max-over-ranks clock, record gather, rank count, line shape - runs with world size 2 without a GPU."""
+
+    def __init__(self, frames, interacted=None):
+        self.t, self.propagated_frames, self.interacted = frames, 0, set()
+
+    def drop_lookahead(self):
+        return 0
+
+    def interact_steps(self, mask, idx, step_cb=None):
+        import numpy as np
+        self.interacted.add(idx)
+        lo = max([i for i in self.interacted if i < idx] + [-1])
+        hi = min([i for i in self.interacted if i > idx] + [self.t])
+        for _ in range(hi - lo - 2):
+            time.sleep(2e-4)
+            self.propagated_frames += 1
+            if step_cb is not None:
+                step_cb()
+            yield
+        return np.zeros((self.t, 4, 4), dtype=np.uint8)
+
+    def interact(self, mask, idx, step_cb=None):
+        g = self.interact_steps(mask, idx, step_cb=step_cb)
+        while True:
+            try:
+                next(g)
+            except StopIteration as e:
+                return e.value
+
+
+CORE_FACTORY = None       # --stub-engine: callable(images, objects) -> StubCore; None = mivos_amd.inference_core.InferenceCore on the GPU
+
+
+def make_core(prop, fuse, images, objects, mem_freq, dev):
+    if CORE_FACTORY is not None:
+        return CORE_FACTORY(images, objects)
+    from mivos_amd.inference_core import InferenceCore
+    return InferenceCore(prop, fuse, images, objects, mem_profile=0, mem_freq=mem_freq, device=dev)
+
+
 class StepClock:
     """step_cb hook: after `warmup` steps drops the look-ahead of the running core, synchronises and stamps t0; stamps
     t1 after exactly `steps` more."""
@@ -69,9 +121,9 @@ class StepClock:
         self.n, self.t0, self.t1, self.samples, self.cores, self.dropped = 0, None, None, [], [], 0
 
     def _stamp(self):
-        self.torch.cuda.synchronize()
+        gpu_sync(self.torch)
         self.shard.barrier()
-        self.torch.cuda.synchronize()
+        gpu_sync(self.torch)
         return time.perf_counter()
 
     def arm(self):
@@ -182,6 +234,69 @@ def lane_streams(torch, dev, lanes):
     if key not in _LANE_STREAMS:
         _LANE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
     return _LANE_STREAMS[key]
+
+
+class ClockSampler:
+    """Background samples of the GPU's shader clock and package power while a measurement runs (rocm-smi --showclocks --showpower --json every
+    ~0.3 s from a thread; the tool is part of the ROCm image and readable by an ordinary user).  `summary()` is None-safe: a box without the tool
+    yields {"available": false, ...} instead of numbers."""
+
+    def __init__(self, device_index=0, period=0.3):
+        import threading
+        self.idx, self.period, self.samples, self.error = device_index, period, [], None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        while not self._stop.is_set():
+            try:
+                txt = subprocess.run(["rocm-smi", "-d", str(self.idx), "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+                card = next(iter(json.loads(txt).values()))
+                sclk = re.search(r"(\d+)", card.get("sclk clock speed:", ""))
+                power = next((v for k, v in card.items() if "Power" in k), None)
+                self.samples.append((time.perf_counter(), int(sclk.group(1)) if sclk else None, float(power) if power is not None else None))
+            except Exception as e:                   # no tool / no permission / unexpected format: the measurement itself must not suffer
+                self.error = repr(e)[:120]
+                return
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=6)
+
+    def summary(self, t0, t1):
+        """Statistics of the samples taken inside [t0, t1] (perf_counter stamps of the timed region)."""
+        inside = [(c, p) for t, c, p in self.samples if t0 <= t <= t1]
+        clk = sorted(c for c, _ in inside if c)
+        pw = sorted(p for _, p in inside if p is not None)
+        if not clk:
+            return dict(available=False, reason=self.error or "no rocm-smi sample fell inside the timed region")
+        return dict(available=True, samples=len(inside), sclk_mhz_median=clk[len(clk) // 2], sclk_mhz_min=clk[0], sclk_mhz_max=clk[-1],
+                    package_power_w_median=pw[len(pw) // 2] if pw else None, package_power_w_max=pw[-1] if pw else None,
+                    source="rocm-smi --showclocks --showpower, sampled from a host thread beside the timed region")
+
+
+def window_phase(cfg, T, warmup, steps, lanes=1):
+    """Where in the repeated session the timed window sits.  A config-3 session is 69 plain steps (interact(0)) followed by 68 fused steps
+    (interact(69)); a window shorter than a session that started at step `warmup` of a session - the driver's --steps 20 --warmup 5 - would hold
+    plain frames only (and a 2-6 frame bank).  `preroll` extra untimed steps are therefore run first so that the window straddles the plain /
+    fused boundary in the session's own proportion (69 : 68) and contains what happens between the two interactions (argmax + D2H of the first,
+    difference maps and memorize of the second).  Windows of a whole session or more, and single-interaction configs, start at step `warmup` as
+    before.  Returns (preroll, plain steps in the window, fused steps in the window)."""
+    inter = len(cfg["interactions"])
+    n_plain = lanes * (T - 1)                      # `lanes` sessions advance in lockstep, a step is a frame of any of them
+    session = n_plain + (lanes * (T - 2) if inter > 1 else 0)
+    if inter < 2 or steps >= session:
+        preroll = 0
+    else:
+        preroll = (n_plain - warmup - int(round(steps * n_plain / session))) % session
+    plain = sum(1 for s in range(preroll + warmup, preroll + warmup + steps) if (s % session) < n_plain)
+    return preroll, plain, steps - plain
 
 
 def event_pair_overhead(torch):
@@ -332,20 +447,19 @@ def cpu_baseline(torch, cfg, images, gt, mem_freq, prop, fuse, dev, n_frames, wi
                 seconds=round(dt, 2), host_cores=os.cpu_count()), parity
 
 
-def run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, mem_freq, warmup, steps, profile_every, lanes=1):
+def run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, mem_freq, warmup, steps, profile_every, lanes=1, preroll=0):
     """Repeat the configuration's session (fresh InferenceCore over the HBM-resident clip) until `warmup + steps` steps
     have run.  Returns (clock, masks of the first session's first interaction).
 
     lanes > 1: that many sessions are in flight on this GPU, each on its own HIP stream, advanced in turn one propagated frame at a
     time (InferenceCore.interact_steps) - what eval_suite.run_suite(lanes=...) does with the clips of a suite.  A step is still one
     propagated frame (of whichever session); the timed region still holds exactly `steps` of them."""
-    from mivos_amd.inference_core import InferenceCore
-    clock = StepClock(warmup, steps, profile_every, ops, shard, torch)
+    clock = StepClock(warmup + preroll, steps, profile_every, ops, shard, torch)      # preroll: see window_phase
     T = images.shape[1]
     first = None
     if lanes <= 1:
         while not clock.done:
-            core = InferenceCore(prop, fuse, images, cfg["objects"], mem_profile=0, mem_freq=mem_freq, device=dev)
+            core = make_core(prop, fuse, images, cfg["objects"], mem_freq, dev)
             clock.cores = [core]
             clock.arm()
             for i in cfg["interactions"]:
@@ -360,7 +474,7 @@ def run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, mem_freq, 
 
         def session_loop(lane):
             while not clock.done:
-                core = InferenceCore(prop, fuse, images, cfg["objects"], mem_profile=0, mem_freq=mem_freq, device=dev)
+                core = make_core(prop, fuse, images, cfg["objects"], mem_freq, dev)
                 clock.cores[lane] = core
                 clock.arm()
                 for i in cfg["interactions"]:
@@ -386,7 +500,7 @@ def run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, mem_freq, 
                             live.remove(lane)
         first = firsts[0]
     ops.PROFILE = None
-    torch.cuda.synchronize()
+    gpu_sync(torch)
     return clock, first
 
 
@@ -397,10 +511,9 @@ def run_full_session(torch, shard, cfg, images, gt, prop, fuse, dev, mem_freq, l
     fused half and the bank's growth ("69 + 68").  Includes the per-interaction work outside the
     do_pass loop (memorize of the interacted frame, final argmax + D2H of the masks).  lanes > 1: that many complete sessions in
     flight, one HIP stream each, advanced in turn frame by frame; steps = the frames of all of them."""
-    from mivos_amd.inference_core import InferenceCore
     T = images.shape[1]
-    cores = [InferenceCore(prop, fuse, images, cfg["objects"], mem_profile=0, mem_freq=mem_freq, device=dev) for _ in range(lanes)]
-    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+    cores = [make_core(prop, fuse, images, cfg["objects"], mem_freq, dev) for _ in range(lanes)]
+    gpu_sync(torch); shard.barrier(); gpu_sync(torch)
     t0 = time.perf_counter()
     per = []
     if lanes <= 1:
@@ -424,12 +537,29 @@ def run_full_session(torch, shard, cfg, images, gt, prop, fuse, dev, mem_freq, l
                         if next(loops[lane], "end") == "end":
                             live.remove(lane)
         per = [lanes * (T - 1)] + [lanes * (T - 2)] * (len(cfg["interactions"]) - 1)
-    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+    gpu_sync(torch); shard.barrier(); gpu_sync(torch)
     dt = time.perf_counter() - t0
     n = sum(c.propagated_frames for c in cores)
     return dict(value=round(n / dt, 3), unit="frames/s", ms_per_step=round(dt / n * 1e3, 3), steps=n, plain=per[0], fused=sum(per[1:]),
                 seconds=round(dt, 4), sessions_in_flight=lanes,
                 note="whole session(s) incl. memorize of the interacted frames and the final argmax + D2H; untimed by --steps/--warmup")
+
+
+def hbm_budget_check(torch, dev, cfg, T, K, lanes, mem_freq):
+    """First-contact guard of the multi-GPU run: what `lanes` sessions of this configuration keep resident per GPU (mem_profile 0) against the
+    free HBM of THIS rank's device, with a one-line reason instead of an out-of-memory error somewhere inside the first session.  Per session:
+    the padded clip (fp32), the probabilities [K+1, T], the cached query features + decoder skip branches of every frame (the dominant
+    term: f16 1024 + f8 512 + f4 256 channels, the three skip maps, key / value, the compress block's partial sums - measured 90 MB per frame
+    at 480p = 217 bytes per padded pixel), two memory banks (fp32 + split keys) of T / mem_freq + 3 slots."""
+    nh, nw = (cfg["height"] + 15) // 16 * 16, (cfg["width"] + 15) // 16 * 16
+    P = nh * nw
+    per_session = T * P * (3 * 4 + (K + 1) * 4) + min(T, 106) * P * 217 + 2 * K * (T // mem_freq + 3) * (P // 256) * (128 * 2 + 512) * 4     # (the query cache holds <= 106 frames)
+    need = lanes * per_session + (3 << 30)                       # + weights, packed plans, workspaces, the allocator's slack
+    free, total = torch.cuda.mem_get_info(torch.device(dev))
+    if need > free:
+        raise SystemExit(f"bench.py: {lanes} session(s) of config {cfg['name']} ({T} frames of {nh}x{nw}, {K} objects) need ~{need / 1e9:.1f} GB resident on {dev}, "
+                         f"{free / 1e9:.1f} of {total / 1e9:.1f} GB are free: lower --lanes / --frames")
+    return need
 
 
 def self_spawn(args_list, n):
@@ -443,6 +573,7 @@ def self_spawn(args_list, n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + args_list
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 1) // n))))      # (torchrun's own default is 1 per rank)
     return subprocess.call(cmd, env=env)
 
 
@@ -461,7 +592,8 @@ def main():
     ap.add_argument("--clips", type=int, default=474, help="config 4: how many of the 474 suite clips to run (default: all; ~4 min on one GPU)")
     ap.add_argument("--lanes", type=int, default=None,
                     help="clips / sessions in flight per GPU, each on its own HIP stream and advanced in turn frame by frame (eval_suite.run_suite(lanes=...), "
-                         "run_sessions(lanes=...)); 1 = one at a time.  Default: DEFAULT_LANES per config (2 for config 3, 3 for configs 2 / 4; env MIVOS_BENCH_LANES), everything else 1")
+                         "run_sessions(lanes=...)).  Configs 2 / 3 / 5: `value` is ALWAYS one session in flight; --lanes > 1 adds the labelled `several_clips_in_flight` "
+                         "fields.  Config 4 (the suite): the lanes of run_suite.  Default: DEFAULT_LANES per config (2 for config 3, 3 for configs 2 / 4; env MIVOS_BENCH_LANES), else 1")
     ap.add_argument("--stub-engine", action="store_true",
                     help="PLUMBING TEST ONLY (tests/test_bench_multirank.py): config 4 with a numpy stand-in for InferenceCore, so that argument "
                          "parsing, self-spawn, sharding, the record gather and the JSON line can be exercised with world_size 2 on a machine "
@@ -473,6 +605,7 @@ def main():
     ap.add_argument("--no-cpu-fp64", dest="cpu_fp64", action="store_false",
                     help="skip the fp64 run of the oracle on the mini session (the arbitration truth of the parity block; ~4x the fp32 oracle's time)")
     ap.add_argument("--no-full-session", action="store_true", help="skip the extra whole-session measurement (configs 2/3) printed as full_session")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the extra >= 5 s measurement with sampled clocks / power (configs 2/3) printed as sustained")
     ap.add_argument("--exact-f32-steps", type=int, default=None,
                     help="steps of the extra exact-fp32-MFMA measurement (CONV_PRECISION='f32'); default one session for config 3, 0 otherwise")
     ap.add_argument("--profile-every", type=int, default=None,
@@ -496,15 +629,23 @@ def main():
     rank, world, local = shard.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # host threads: N ranks on one node must not each start a thread per host core (256 on the GPU boxes) for torch's CPU ops
+    # (clip generation, the one-hot masks); the CPU-oracle leg (rank 0 of a single-process run only) sets its own count
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 1) // max(world, 1))))
     if args.stub_engine:
-        if args.config != 4:
-            raise SystemExit("--stub-engine is the config-4 plumbing test")
-        return bench_suite(args, torch, ops, shard, rank, world, "cpu")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    local = local % torch.cuda.device_count()      # (more ranks than GPUs only in the MIVOS_DIST_BACKEND=gloo plumbing test)
-    torch.cuda.set_device(local)
-    dev = f"cuda:{local}"
+        if args.config == 4:
+            return bench_suite(args, torch, ops, shard, rank, world, "cpu")
+        if args.config not in (2, 3, 5):
+            raise SystemExit("--stub-engine is the plumbing test of configs 2 / 3 / 4 / 5")
+        global CORE_FACTORY
+        CORE_FACTORY = lambda images, objects: StubCore(images.shape[1])
+        dev, args.lanes = "cpu", 1
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+        local = local % torch.cuda.device_count()      # (more ranks than GPUs only in the MIVOS_DIST_BACKEND=gloo plumbing test)
+        torch.cuda.set_device(local)
+        dev = f"cuda:{local}"
 
     if args.config == 4:
         return bench_suite(args, torch, ops, shard, rank, world, dev)
@@ -524,11 +665,19 @@ def main():
     cpu_frames = args.cpu_frames if args.cpu_frames is not None else (2 if args.config == 5 else 6)
     exact_steps = args.exact_f32_steps if args.exact_f32_steps is not None else (session - 8 if args.config == 3 else 0)
 
-    prop, fuse = PropagationNetwork(top_k=cfg["top_k"]), FusionNet()
-    prop.load_state_dict(bench_states(synthetic)[0])
-    fuse.load_state_dict(bench_states(synthetic)[1])
-    prop, fuse = prop.to(dev).eval(), fuse.to(dev).eval()
-    if T * cfg["height"] * cfg["width"] > 70 * 480 * 864:
+    if args.stub_engine:
+        prop = fuse = None
+        images, gt = torch.zeros((1, T, 1, 1, 1)), [None] * T
+        exact_steps = cpu_frames = 0
+    else:
+        hbm_budget_check(torch, dev, cfg, T, K, max(1, args.lanes), args.mem_freq)
+        prop, fuse = PropagationNetwork(top_k=cfg["top_k"]), FusionNet()
+        prop.load_state_dict(bench_states(synthetic)[0])
+        fuse.load_state_dict(bench_states(synthetic)[1])
+        prop, fuse = prop.to(dev).eval(), fuse.to(dev).eval()
+    if args.stub_engine:
+        pass
+    elif T * cfg["height"] * cfg["width"] > 70 * 480 * 864:
         images, gt = synthetic.synthetic_clip_device(T, cfg["height"], cfg["width"], K, seed=100 + rank, device=dev)
     else:
         images, gt = synthetic.synthetic_clip(T, cfg["height"], cfg["width"], K, seed=100 + rank)
@@ -536,34 +685,61 @@ def main():
 
     if args.profile_every is None:
         args.profile_every = 21 if steps >= 400 else (7 if steps >= 40 else 3)
-    # per-launch HIP-event samples (roofline) are taken with ONE session in flight: beside another stream's kernels an event pair also
-    # measures the CUs the neighbour holds
-    clock, masks_first = run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, warmup, steps,
-                                      args.profile_every if args.lanes <= 1 else 0, lanes=args.lanes)
+    # HEADLINE: ONE session (clip) in flight - the reference's workload is one interactive session at a time (and rounds 1-4 measured that).
+    # The per-launch HIP-event samples (roofline) are taken in this pass too: beside another stream's kernels an event pair would also
+    # measure the CUs the neighbour holds.  Several clips in flight per GPU (--lanes) is a separate, labelled field below.
+    preroll, n_plain, n_fused = window_phase(cfg, T, warmup, steps)
+    sustained_is_headline = args.config in (2, 3) and steps >= 5 * session        # the default `python bench.py` (8 sessions): the headline IS sustained
+    with ClockSampler(local) as smi:
+        clock, masks_first = run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, warmup, steps, args.profile_every, lanes=1, preroll=preroll)
     elapsed = shard.max_over_ranks(clock.t1 - clock.t0, device=dev)
-    one_lane, samples = None, clock.samples
-    if args.lanes > 1:                      # the same window with ONE session in flight (the figure of rounds 1-4)
-        c1, _ = run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, warmup, steps, args.profile_every, lanes=1)
-        e1 = shard.max_over_ranks(c1.t1 - c1.t0, device=dev)
-        one_lane = dict(value=round(world * steps / e1, 3), unit="frames/s", ms_per_step=round(e1 / steps * 1e3, 3), steps=steps, warmup=warmup,
-                        note="same window, one session in flight; the roofline samples of this line come from this pass")
-        samples = c1.samples
+    headline_clocks = smi.summary(clock.t0, clock.t1) if rank == 0 else None
+    samples = clock.samples
+    several = None
+    if args.lanes > 1:                      # the same window with `lanes` sessions in flight, each on its own HIP stream (the suite mode of eval_suite.run_suite)
+        pre_n, pl_n, fu_n = window_phase(cfg, T, warmup, steps, lanes=args.lanes)
+        cn, _ = run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, warmup, steps, 0, lanes=args.lanes, preroll=pre_n)
+        en = shard.max_over_ranks(cn.t1 - cn.t0, device=dev)
+        several = dict(sessions_in_flight=args.lanes, value=round(world * steps / en, 3), unit="frames/s", ms_per_step=round(en / steps * 1e3, 3), steps=steps, warmup=warmup,
+                       untimed_steps_before_warmup=pre_n, plain_steps=pl_n, fused_steps=fu_n,
+                       note=f"same window with {args.lanes} sessions in flight per GPU, one HIP stream each, advanced in turn frame by frame (a step is one propagated frame of "
+                            "any of them): aggregate throughput of independent clips (eval_suite.run_suite(lanes=...)), NOT the latency of one interactive session")
     recs = shard.gather_records([dict(rank=rank, steps=steps, seconds=round(clock.t1 - clock.t0, 6))])
     ranks_seen = shard.collective_ranks(dev)
-    mem_gb = torch.cuda.max_memory_allocated() / 1e9
+    mem_gb = torch.cuda.max_memory_allocated() / 1e9 if torch.cuda.is_available() else 0.0
     full = None
     if args.config in (2, 3) and not args.no_full_session:
         full = run_full_session(torch, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq)
         full["seconds"] = round(shard.max_over_ranks(full["seconds"], device=dev), 4)
         full["value"] = round(world * full["steps"] / full["seconds"], 3)
         full["ms_per_step"] = round(full["seconds"] / full["steps"] * 1e3, 3)
-        if args.lanes > 1:                  # `lanes` complete sessions in flight; the single-session figure stays next to it
+        if args.lanes > 1:                  # `lanes` complete sessions in flight, next to the single-session figure
             multi = run_full_session(torch, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, lanes=args.lanes)
             multi["seconds"] = round(shard.max_over_ranks(multi["seconds"], device=dev), 4)
             multi["value"] = round(world * multi["steps"] / multi["seconds"], 3)
             multi["ms_per_step"] = round(multi["seconds"] / multi["steps"] * 1e3, 3)
-            multi["one_clip_in_flight"] = full
-            full = multi
+            full["several_clips_in_flight"] = multi
+    # SUSTAINED: >= 5 s of whole sessions (8 sessions of config 3, 16 of config 2) with the shader clock and the package power sampled beside them - the
+    # driver's 20-step window lasts 0.1 s and runs at the boost clock (2.4 GHz); after about a second under this load the chip settles at 1.9 GHz
+    sustained = None
+    if args.config in (2, 3) and not args.no_sustained:
+        if sustained_is_headline:
+            sustained = dict(value=round(world * steps / elapsed, 3), unit="frames/s", ms_per_step=round(elapsed / steps * 1e3, 3), steps=steps, seconds=round(elapsed, 3),
+                             sessions_in_flight=1, clocks=headline_clocks, note="the headline window itself (>= 4 s)")
+        else:
+            n_sess = 8 if args.config == 3 else 16
+            sustained = {}
+            for ln in sorted({1, args.lanes}):
+                with ClockSampler(local) as smi2:
+                    cs, _ = run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, session, n_sess * session, 0, lanes=ln)
+                es = shard.max_over_ranks(cs.t1 - cs.t0, device=dev)
+                rec = dict(value=round(world * n_sess * session / es, 3), unit="frames/s", ms_per_step=round(es / (n_sess * session) * 1e3, 3), steps=n_sess * session,
+                           warmup=session, seconds=round(es, 3), sessions_in_flight=ln, clocks=smi2.summary(cs.t0, cs.t1) if rank == 0 else None)
+                if ln == 1:
+                    sustained.update(rec)
+                    sustained["note"] = f"{n_sess} whole sessions after one untimed session, one session in flight (the headline's mode), clock and power sampled beside the timed region"
+                else:
+                    sustained["several_clips_in_flight"] = rec
 
     exact = None
     if exact_steps > 0 and rank == 0 and world == 1:
@@ -573,6 +749,14 @@ def main():
         exact = dict(value=round(exact_steps / (c2.t1 - c2.t0), 3), unit="frames/s", ms_per_step=round((c2.t1 - c2.t0) / exact_steps * 1e3, 3),
                      steps=exact_steps, warmup=8, dtype="f32 (every convolution and the affinity on exact fp32 MFMA, CONV_PRECISION='f32')")
     if rank != 0:
+        return
+    if args.stub_engine:          # plumbing line: the keys of the real line that do not need a GPU
+        print(json.dumps(dict(metric="plumbing test (numpy stand-in engine): not a measurement", value=round(world * steps / elapsed, 3), unit="frames/s", n_gpus=world, steps=steps,
+                              warmup=warmup, ms_per_step=round(elapsed / steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="none", data="synthetic",
+                              stub_engine=True, config=dict(workload=f"{cfg['name']} (BASELINE config {args.config}) with a numpy stand-in for InferenceCore", baseline_config=args.config,
+                                                            session_steps=session, untimed_steps_before_warmup=preroll, plain_steps=n_plain, fused_steps=n_fused,
+                                                            parallelism=f"sequence-sharded x{world}", clips_in_flight_per_gpu=1),
+                              full_session=full, sustained=sustained, roofline=None, cpu_baseline=None, per_rank=recs, **ranks_seen)))
         return
     ev_overhead = event_pair_overhead(torch)
     # the select instantiation that serves this configuration's banks (csrc/memory_read.hip launch_select: the 256-query kernel
@@ -596,8 +780,10 @@ def main():
         # With several clips in flight per GPU a per-launch event pair cannot see what the neighbour stream adds; this figure does.
         per_frame = {2: 0.47, 3: 1.34}.get(args.config)        # (config 5's 14.7 TFLOP is the figure at the full 200-frame bank; the bank grows over the run)
         if per_frame and ops.CONV_PRECISION == "f16x3":
+            fused_extra = {2: 0.03, 3: 0.16}[args.config]        # attention + FusionNet of a fused frame (1.50 - 1.34 TFLOP at 5 objects)
+            per_frame = round((n_plain * per_frame + n_fused * (per_frame + fused_extra)) / steps, 4)
             ach = per_frame * (steps / elapsed)
-            roof["timed_region"] = dict(algorithmic_tflop_per_frame=per_frame, frames_per_second_per_gpu=round(steps / elapsed, 3), achieved=round(ach, 2),
+            roof["timed_region"] = dict(algorithmic_tflop_per_frame=per_frame, plain_steps=n_plain, fused_steps=n_fused, frames_per_second_per_gpu=round(steps / elapsed, 3), achieved=round(ach, 2),
                                         peak=round(F16X3_PEAK_TFLOPS, 1), unit="TFLOP/s", frac=round(ach / F16X3_PEAK_TFLOPS, 4),
                                         note="all kernels of the timed region together (HBM-bound pointwise kernels, selection, launch gaps included)")
         # In the timed region the fusion branch of frame t runs on a side stream BESIDE the propagation kernels of frame t + 1
@@ -654,13 +840,15 @@ def main():
                data="synthetic",
                config=dict(workload=f"{cfg['name']} (BASELINE config {args.config}): {cfg['height']}x{cfg['width']} clip of {T} frames per GPU, {K} objects, "
                                     f"top_k={cfg['top_k']}, mem_freq={args.mem_freq}; session = interact at frames {inter} = {session} steps "
-                                    f"({T - 1} plain" + (f" + {T - 2} fused" if len(inter) > 1 else "") + f"); timed steps {warmup}..{warmup + steps} of the repeated session"
-                                    + (f"; {args.lanes} sessions in flight per GPU (one HIP stream each, advanced in turn frame by frame; a step is one propagated frame of either)" if args.lanes > 1 else ""),
+                                    f"({T - 1} plain" + (f" + {T - 2} fused" if len(inter) > 1 else "") + f"); ONE session in flight; timed steps {preroll + warmup}..{preroll + warmup + steps} of the "
+                                    f"repeated session = {n_plain} plain + {n_fused} fused"
+                                    + (f" ({preroll} untimed steps run before the {warmup} warm-up steps so that the window straddles the plain / fused boundary in the session's proportion)" if preroll else ""),
                            baseline_config=args.config, objects=K, frames=T, height=cfg["height"], width=cfg["width"], top_k=cfg["top_k"],
                            mem_freq=args.mem_freq, session_steps=session, sessions_timed=round(steps / session, 3),
                            prepaid_frames=0, lookahead_entries_dropped_at_t0=clock.dropped, parallelism=f"sequence-sharded x{world}",
-                           clips_in_flight_per_gpu=args.lanes),
-               one_clip_in_flight=one_lane, roofline=roof, full_session=full, conv_kernels=table, exact_f32=exact, hbm_peak_allocated_gb=round(mem_gb, 2), per_rank=recs, **ranks_seen)
+                           clips_in_flight_per_gpu=1, untimed_steps_before_warmup=preroll, plain_steps=n_plain, fused_steps=n_fused),
+               clocks=headline_clocks, several_clips_in_flight=several, sustained=sustained, roofline=roof, full_session=full, conv_kernels=table, exact_f32=exact,
+               hbm_peak_allocated_gb=round(mem_gb, 2), per_rank=recs, **ranks_seen)
     if world == 1 and cpu_frames > 1:
         out["cpu_baseline"], out["parity"] = cpu_baseline(torch, cfg, images, gt, args.mem_freq, prop, fuse, dev, cpu_frames, args.cpu_fp64)
     else:

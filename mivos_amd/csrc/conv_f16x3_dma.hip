@@ -400,6 +400,12 @@ static int launch_pp(ConvP &p, hipStream_t st) {
   if (force_slices && p.vec_epi && p.ws && (long long)force_slices * p.M * p.Cout * 4 <= p.ws_bytes && nk >= 2 * force_slices) slices = force_slices;
   p.kt_split = 0;
   if (slices > 1) { p.kt_split = cdiv(nk, slices); slices = cdiv(nk, p.kt_split); p.partial = (float *)p.ws; }
+  // profiling only (scripts/insitu_shape_table.py): one line per launch, in host order, to join with a rocprofv3 kernel trace by dispatch order
+  static FILE *const shape_log = getenv("MIVOS_CONV_LOG") ? fopen(getenv("MIVOS_CONV_LOG"), "a") : nullptr;
+  if (shape_log) {
+    fprintf(shape_log, "pp %d %d %d %d %d %d %d %d %d %d %d %d\n", BM, BN, p.M, p.Cin, p.Cout, p.KH, p.stride, p.res ? 1 : 0, slices, tiles_m * p.tiles_n, p.share, p.y_fmt);
+    fflush(shape_log);
+  }
   hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n, slices), dim3(512), lds, st, p, (unsigned)x_bytes, (unsigned)w_bytes);
   if (slices > 1) return launch_splitk_reduce(p, slices, st);
   return check_launch("conv_f16x3_pp");
