@@ -286,7 +286,7 @@ def window_phase(cfg, T, warmup, steps, lanes=1):
     (interact(69)); a window shorter than a session that started at step `warmup` of a session - the driver's --steps 20 --warmup 5 - would hold
     plain frames only (and a 2-6 frame bank).  `preroll` extra untimed steps are therefore run first so that the window straddles the plain /
     fused boundary in the session's own proportion (69 : 68) and contains what happens between the two interactions (argmax + D2H of the first,
-    difference maps and memorize of the second).  Windows of a whole session or more, and single-interaction configs, start at step `warmup` as
+    difference maps and memorize of the second); the preroll starts with one whole session (first-use costs of the fused half).  Windows of a whole session or more, and single-interaction configs, start at step `warmup` as
     before.  Returns (preroll, plain steps in the window, fused steps in the window)."""
     inter = len(cfg["interactions"])
     n_plain = lanes * (T - 1)                      # `lanes` sessions advance in lockstep, a step is a frame of any of them
@@ -294,7 +294,9 @@ def window_phase(cfg, T, warmup, steps, lanes=1):
     if inter < 2 or steps >= session:
         preroll = 0
     else:
-        preroll = (n_plain - warmup - int(round(steps * n_plain / session))) % session
+        # one whole untimed session first: everything the fused half uses for the first time in a process (FusionNet's plan and workspaces, the
+        # attention kernels, the page-locked result buffer of the first finished interaction) must not be charged to a 20-step window
+        preroll = session + (n_plain - warmup - int(round(steps * n_plain / session))) % session
     plain = sum(1 for s in range(preroll + warmup, preroll + warmup + steps) if (s % session) < n_plain)
     return preroll, plain, steps - plain
 
@@ -526,7 +528,9 @@ def run_full_session(torch, shard, cfg, images, gt, prop, fuse, dev, mem_freq, l
         def session(core):
             for i in cfg["interactions"]:
                 yield from core.interact_steps(gt[i % T], i % T)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        streams = lane_streams(torch, dev, lanes)
+        for st_ in streams:
+            st_.wait_stream(torch.cuda.current_stream())
         from mivos_amd import ops
         loops = [session(c) for c in cores]
         live = list(range(lanes))
@@ -606,6 +610,8 @@ def main():
                     help="skip the fp64 run of the oracle on the mini session (the arbitration truth of the parity block; ~4x the fp32 oracle's time)")
     ap.add_argument("--no-full-session", action="store_true", help="skip the extra whole-session measurement (configs 2/3) printed as full_session")
     ap.add_argument("--no-sustained", action="store_true", help="skip the extra >= 5 s measurement with sampled clocks / power (configs 2/3) printed as sustained")
+    ap.add_argument("--other-configs", action=argparse.BooleanOptionalAction, default=os.environ.get("MIVOS_BENCH_EXTRAS", "1") != "0",
+                    help="single-GPU config-3 runs only: append short runs of configs 2 / 4 / 5 on the same box as `other_configs` (default on; ~2.5 min)")
     ap.add_argument("--exact-f32-steps", type=int, default=None,
                     help="steps of the extra exact-fp32-MFMA measurement (CONV_PRECISION='f32'); default one session for config 3, 0 otherwise")
     ap.add_argument("--profile-every", type=int, default=None,
@@ -741,6 +747,17 @@ def main():
                 else:
                     sustained["several_clips_in_flight"] = rec
 
+    if sustained and sustained.get("value") and args.config in (2, 3) and not args.stub_engine:
+        # the whole sustained region against the f16x3 roofline, at the nominal 2.4 GHz and at the shader clock the sampler saw (the matrix pipes' peak
+        # scales with it: under this load the chip holds ~1.9 GHz, MI355X_MICROARCH.md quotes the peak at 2.4)
+        base, extra = {2: (0.47, 0.03), 3: (1.34, 0.16)}[args.config]
+        pf = (base * (T - 1) + (base + extra) * (T - 2) * (len(cfg["interactions"]) - 1)) / session
+        ach = pf * sustained["value"] / world
+        clk = (sustained.get("clocks") or {}).get("sclk_mhz_median")
+        sustained["roofline_timed_region"] = dict(algorithmic_tflop_per_frame=round(pf, 4), achieved=round(ach, 2), peak=round(F16X3_PEAK_TFLOPS, 1), unit="TFLOP/s",
+                                                  frac=round(ach / F16X3_PEAK_TFLOPS, 4), nominal_clock_mhz=2400, sampled_clock_mhz=clk,
+                                                  frac_at_sampled_clock=round(ach / (F16X3_PEAK_TFLOPS * clk / 2400.0), 4) if clk else None)
+
     exact = None
     if exact_steps > 0 and rank == 0 and world == 1:
         old, ops.CONV_PRECISION = ops.CONV_PRECISION, "f32"
@@ -840,9 +857,10 @@ def main():
                data="synthetic",
                config=dict(workload=f"{cfg['name']} (BASELINE config {args.config}): {cfg['height']}x{cfg['width']} clip of {T} frames per GPU, {K} objects, "
                                     f"top_k={cfg['top_k']}, mem_freq={args.mem_freq}; session = interact at frames {inter} = {session} steps "
-                                    f"({T - 1} plain" + (f" + {T - 2} fused" if len(inter) > 1 else "") + f"); ONE session in flight; timed steps {preroll + warmup}..{preroll + warmup + steps} of the "
-                                    f"repeated session = {n_plain} plain + {n_fused} fused"
-                                    + (f" ({preroll} untimed steps run before the {warmup} warm-up steps so that the window straddles the plain / fused boundary in the session's proportion)" if preroll else ""),
+                                    f"({T - 1} plain" + (f" + {T - 2} fused" if len(inter) > 1 else "") + f"); ONE session in flight; timed steps {(preroll + warmup) % session}..{(preroll + warmup) % session + steps} of "
+                                    f"the repeated session = {n_plain} plain + {n_fused} fused"
+                                    + (f" ({preroll} untimed steps - one whole session + {preroll - session} - run before the {warmup} warm-up steps so that the window straddles the plain / fused "
+                                       f"boundary in the session's proportion and holds no first-use cost)" if preroll else ""),
                            baseline_config=args.config, objects=K, frames=T, height=cfg["height"], width=cfg["width"], top_k=cfg["top_k"],
                            mem_freq=args.mem_freq, session_steps=session, sessions_timed=round(steps / session, 3),
                            prepaid_frames=0, lookahead_entries_dropped_at_t0=clock.dropped, parallelism=f"sequence-sharded x{world}",
@@ -853,7 +871,43 @@ def main():
         out["cpu_baseline"], out["parity"] = cpu_baseline(torch, cfg, images, gt, args.mem_freq, prop, fuse, dev, cpu_frames, args.cpu_fp64)
     else:
         out["cpu_baseline"] = None
+    if args.other_configs and world == 1 and args.config == 3 and cpu_frames > 1:      # (the full line only: tuning runs pass --cpu-frames 0)
+        del images, gt, clock, samples
+        torch.cuda.empty_cache()
+        out["other_configs"] = other_configs()
     print(json.dumps(out))
+
+
+def other_configs():
+    """The other BASELINE configurations on the SAME box, each as a short run of this script in a fresh process (clean allocator, nothing shared
+    with the headline measurement), summarised: config 2 (one session + whole sessions), config 4 (the first 48 clips of the suite, 3 clips in
+    flight), config 5 (the full 1000-frame 1080p clip, bank growing to 200 frames).  Only in the default single-GPU config-3 run (--other-configs /
+    MIVOS_BENCH_EXTRAS=0 to skip); a run that fails or exceeds its time limit is recorded as an error string - it must never cost the line."""
+    runs = {"config2": ["--config", "2", "--cpu-frames", "0"],        # default window: 8 sessions after one untimed session
+            "config4_48clips": ["--config", "4", "--clips", "48"],
+            "config5": ["--config", "5", "--cpu-frames", "0"]}
+    res = {}
+    for name, extra in runs.items():
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra, capture_output=True, text=True, timeout=300)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                res[name] = dict(error=(r.stderr or r.stdout)[-300:])
+                continue
+            d = json.loads(lines[-1])
+            rec = dict(value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"], steps=d["steps"], warmup=d["warmup"], workload=d["config"]["workload"][:160],
+                       clips_in_flight_per_gpu=d["config"].get("clips_in_flight_per_gpu"), wall_seconds=round(time.perf_counter() - t0, 1))
+            for k in ("several_clips_in_flight", "full_session"):
+                if d.get(k):
+                    rec[k] = {kk: d[k].get(kk) for kk in ("value", "ms_per_step", "steps", "sessions_in_flight")}
+            aff = ((d.get("roofline") or {}).get("affinity") or {})
+            if aff:
+                rec["affinity"] = {kk: aff.get(kk) for kk in ("frac", "achieved", "avg_launch_us")}
+            res[name] = rec
+        except Exception as e:
+            res[name] = dict(error=repr(e)[:300])
+    return res
 
 
 def bench_suite(args, torch, ops, shard, rank, world, dev):

@@ -100,14 +100,14 @@ typedef struct {
   int32_t dilation;    /* spacing of the kernel taps (0 or 1: dense).  DeepLab's atrous convolutions (model/s2m/_deeplab.py:
                           110-118, s2m_resnet.py:17-20) use 2 / 6 / 12 / 18 with pad == dilation; precision 0 / 1 only.       */
   int32_t chip_share;  /* how many independent launch streams the caller keeps busy on this GPU (0 or 1: this launch has the
-                          chip to itself).  A hint for the launch geometry only: with n > 1 the split-K heuristics of precision 2
-                          count on 1/n of the workgroup slots (a second clip's launches fill the rest; splitting K to fill them
-                          would only add partial-sum traffic).  Results are the same up to the fp32 summation order a different
-                          number of K slices implies (rounding level, like a different batch size).                            */
+                          chip to itself).  A hint that must NEVER change results: since round 6 the convolutions ignore it (the
+                          split-K slice count = the fp32 summation order is a function of the layer shape alone; round 5's
+                          share-dependent rule made a clip's masks depend on the number of clips in flight).  Kept in the
+                          descriptor for ABI stability and for geometry decisions that leave the arithmetic untouched.          */
   uint32_t *status;    /* optional device word (4-byte aligned, zeroed by the caller; NULL: off).  Precision 1 / 2 only: the
                           epilogue ORs bit 0 into it when an output value leaves the fp16 range (|y| > 65504) - such a value
                           becomes inf in the hi half of the next layer's operand split, and the ReLUs / clamps downstream would
-                          hide the NaNs that follow.  One atomic per offending workgroup; nothing is written otherwise.         */
+                          hide the NaNs that follow.  One atomic per offending wavefront; nothing is written otherwise.         */
 } mivos_conv_desc;
 
 int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream);
@@ -304,7 +304,9 @@ int mivos_memory_read_set_hifirst(int on);
  * 155 KB of LDS, so with one per CU nothing else runs while the launch lasts; a caller that keeps several launch streams busy on the GPU
  * (several clips in flight) sets CUs / streams and the launches of the other streams run beside it (+3.4 % frames/s with two 480p
  * sessions in flight, profiles/r05e_select_workgroups_ab.txt).  The candidate lists follow the work partition; results are identical.
- * Returns the previous value; negative = only query. */
+ * Process-wide and not synchronised with launches: a select launch reads it once, and the finalize launch on the same workspace uses the
+ * partition that select recorded (not the current value), so changing it between the two is harmless; it must not be changed from another
+ * thread WHILE a select call is computing its plan.  Returns the previous value; negative = only query. */
 int mivos_memory_read_set_workgroups(int n_wg);
 int mivos_memory_read_select(const float *keys, int64_t keys_ostride, const float *qk, int n_obj,
                              int64_t n_mem, int n_q, int top_k, void *workspace, int64_t workspace_bytes,

@@ -17,7 +17,8 @@ struct ConvP {
   int x_border;                        // zero pixels guaranteed around every input image (precision 2 needs >= pad)
   int y_fmt, r_fmt;                    // 0: fp32, 1: SH32 (fp16 hi | lo lines per 32 channels, conv_f16x3_dma.hip)
   int dil;                             // tap spacing (atrous convolution), >= 1
-  int share;                           // launch streams the caller keeps busy on this GPU (>= 1): geometry hint, never changes results
+  int share;                           // launch streams the caller keeps busy on this GPU (>= 1): a hint for launch geometry that must not change results
+                                       // (round 6: the LDS-DMA kernels' split-K slicing, i.e. the fp32 summation order, no longer looks at it)
   unsigned *status;                    // optional device word: bit 0 is set when an output of an f16x3 launch leaves the fp16 range (|y| > 65504)
 };
 
@@ -28,7 +29,9 @@ __device__ __forceinline__ float range_max(float amax, f32x4 v) {
   return fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
 __device__ __forceinline__ void range_flag(const ConvP &p, float amax) {
-  if (p.status && amax > 65504.f) atomicOr(p.status, 1u);
+  if (!p.status) return;
+  const unsigned long long m = __ballot(amax > 65504.f);          // lanes of this wavefront that stored an out-of-range value
+  if (m && (int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicOr(p.status, 1u);   // one atomic per offending wavefront (all blocks are 1-D)
 }
 
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
@@ -93,7 +96,7 @@ __device__ __forceinline__ void epilogue_scalar(const f32x16 (&acc)[MT][NT], con
         if (m >= p.M) continue;
         const int img = m / p.HoWo, pix = m - img * p.HoWo;
         const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
-        float v = acc[i][j][r] * sc + bi;
+        float v = __builtin_fmaf(acc[i][j][r], sc, bi);      // (explicit fma in every epilogue and in splitk_finish4: one rounding, the same bits on every path)
         if (p.res) v += p.res[(long long)img * p.r_ns + (long long)oh * p.r_rs + (long long)ow * p.r_ps + n];
         if (p.relu_out) v = fmaxf(v, 0.f);
         amax = fmaxf(amax, fabsf(v));
@@ -158,7 +161,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float 
         for (int ps = 0; ps < 4; ++ps) {
           f32x4 v = *reinterpret_cast<const f32x4 *>(scratch + (ps * 8 + prow0) * EPI_PITCH + c4);
           if (ok[ii][ps]) {
-            v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
+            v.x = __builtin_fmaf(v.x, sc.x, bi.x); v.y = __builtin_fmaf(v.y, sc.y, bi.y); v.z = __builtin_fmaf(v.z, sc.z, bi.z); v.w = __builtin_fmaf(v.w, sc.w, bi.w);
             if (!PREFETCH && p.res) {
               const int m = m_base + (i0 + ii) * 32 + ps * 8 + prow0;
               const int img = m / p.HoWo, pix = m - img * p.HoWo;
@@ -245,7 +248,7 @@ __device__ __forceinline__ void epilogue_sh32(const f32x16 (&acc)[MT][NT], float
             half8_t hi, lo;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-              float t = v[q] * sc[q] + bi[q];
+              float t = __builtin_fmaf(v[q], sc[q], bi[q]);
               t += rr[ii][ps][q];
               t = p.relu_out ? fmaxf(t, 0.f) : t;
               amax = fmaxf(amax, fabsf(t));
@@ -275,13 +278,18 @@ __device__ __forceinline__ void splitk_finish4(const ConvP &p, int n_slices, int
   }
   const int img = m / p.HoWo, pix = m - img * p.HoWo;
   const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
-  if (p.scale) { const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + n); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
-  if (p.bias) { const f32x4 bi = *reinterpret_cast<const f32x4 *>(p.bias + n); v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }
+  // the SAME arithmetic, operation for operation, as the in-kernel epilogues (epilogue_vec / epilogue_sh32): fma(sum, scale | 1, bias | 0) + (residual | 0),
+  // so that a layer gives the same bits whether its K slices ran as separate workgroups + this pass or one after the other inside one workgroup
+  // (conv_f16x3_pp_kernel<..., FOLD>: what a launch does when other streams share the chip)
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f}, rr = {0.f, 0.f, 0.f, 0.f};
+  if (p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + n);
+  if (p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + n);
   if (p.res) {
     const long long ro = (long long)img * p.r_ns + (long long)oh * p.r_rs + (long long)ow * p.r_ps;
-    const f32x4 rr = p.r_fmt ? load_sh32x4(p.res, ro, n) : *reinterpret_cast<const f32x4 *>(p.res + ro + n);
-    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+    rr = p.r_fmt ? load_sh32x4(p.res, ro, n) : *reinterpret_cast<const f32x4 *>(p.res + ro + n);
   }
+  v.x = __builtin_fmaf(v.x, sc.x, bi.x); v.y = __builtin_fmaf(v.y, sc.y, bi.y); v.z = __builtin_fmaf(v.z, sc.z, bi.z); v.w = __builtin_fmaf(v.w, sc.w, bi.w);
+  v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
   if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
   range_flag(p, range_max(0.f, v));
   float *dst;

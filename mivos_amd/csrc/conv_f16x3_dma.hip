@@ -48,9 +48,15 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 constexpr int ROWB = 128;   // bytes per tile row and K step: 32 k x (hi, lo) fp16
 constexpr unsigned OOB_OFFSET = 0x80000000u;   // + any step offset stays >= num_records (< 2 GB) without wrapping
 
-template <int BM, int BN, int WGM, int WGN, int ABL = 0>   // ABL: profiling ablations (1: no DMA, 2: no DMA wait, 3: no fragment reads); 9: experimental merged-half-step schedule
+// FOLD: the K slices of a split-K layer run ONE AFTER THE OTHER inside this workgroup instead of as gridDim.y workgroups + splitk_reduce_kernel: every
+// p.kt_split steps the accumulator chain is closed (tot += acc, in ascending slice order; acc restarts from zero) and the epilogue works on the total.
+// Same chains, same order of the same fp32 additions as the split launch + reduce pass => the same bits (tests/test_gpu_ops.py); what a launch does when the
+// caller says other streams share the chip (mivos_conv_desc.chip_share > 1): no partial-sum round trip, no reduce launch, no workgroups in slots a
+// neighbour stream would fill.  Costs MT*NT*16 more VGPRs (128x128 tile: 115 -> ~150, one workgroup per CU - the grids that split leave 3/4 of the CUs free anyway).
+template <int BM, int BN, int WGM, int WGN, int ABL = 0, bool FOLD = false>   // ABL: profiling ablations (1: no DMA, 2: no DMA wait, 3: no fragment reads); 9: experimental merged-half-step schedule
 __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_bytes, unsigned w_bytes) {
   static_assert(WGM * WGN == 8, "8 waves per workgroup");
+  static_assert(!FOLD || ABL == 0, "the folded variant exists for the product schedule only");
   static_assert(BM % 64 == 0 && BN % 64 == 0, "tile rows are fetched 64 at a time");
   constexpr int TM = BM / WGM, TN = BN / WGN;
   constexpr int MT = TM / 32, NT = TN / 32;
@@ -91,12 +97,22 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
   }
 
   f32x16 acc[MT][NT];
+  f32x16 tot[MT][NT];          // FOLD only (dead code otherwise): sum of the closed K slices
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.f; if (FOLD) tot[a][b][r] = 0.f; }
+  int fold_left = p.kt_split;  // FOLD: K steps until the running slice ends
+  auto fold = [&]() {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { tot[a][b][r] += acc[a][b][r]; acc[a][b][r] = 0.f; }
+  };
 
   // ---- LDS-DMA issue: scalar state only --------------------------------------------------------------
   const int lds0 = __builtin_amdgcn_readfirstlane((int)(size_t)smem) + wave * 1024;
@@ -105,7 +121,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
   // split-K (small-M layers): gridDim.y slices of kt_split K steps each; raw partial tiles go to p.partial
   const int nk_all = (p.Cin >> 5) * ntaps;
   const int kt0 = p.kt_split ? (int)blockIdx.y * p.kt_split : 0;
-  const int nk = (p.kt_split && kt0 + p.kt_split < nk_all ? kt0 + p.kt_split : nk_all) - kt0;      // steps of this slice
+  const int nk = FOLD ? nk_all : (p.kt_split && kt0 + p.kt_split < nk_all ? kt0 + p.kt_split : nk_all) - kt0;      // steps of this slice (FOLD: all slices, in turn)
   const int b_step = p.Cout * ROWB;
   int a_tap = kt0 % ntaps, a_kw = a_tap % p.KW;                         // activation stream: tap / slab of its next step
   int a_tap_off = ((a_tap / p.KW) * (int)(p.x_rs * 4)) + a_kw * pix_step, a_slab_off = (kt0 / ntaps) * ROWB;
@@ -236,6 +252,9 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
     phase_barrier();
     mfma_phase();                                              // M(kt, 1)
     phase_barrier();
+    if constexpr (FOLD) {                                      // wave-uniform: every wave counts its own steps
+      if (--fold_left == 0) { fold_left = p.kt_split; fold(); }
+    }
   };
   using std::integral_constant;
   typedef std::false_type steady;
@@ -275,7 +294,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
     reinterpret_cast<long long *>(p.ws)[0] = __builtin_readcyclecounter() - t_start;
     reinterpret_cast<long long *>(p.ws)[1] = nk;
   }
-  if (p.kt_split) {                      // raw fp32 partial tile of this K slice: [slice][M][Cout], dense
+  if (!FOLD && p.kt_split) {             // raw fp32 partial tile of this K slice: [slice][M][Cout], dense
     ConvP q = p;
     q.scale = q.bias = q.res = nullptr;
     q.status = nullptr;                    // partial sums are not outputs: the reduce kernel checks the finished values
@@ -291,9 +310,11 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
   }
   // tiles that fit two workgroups per CU (<= 80 KB LDS) must also stay within 128 VGPRs: prefetch one row tile at a time
   constexpr int EIB = (3 * BM + 2 * BN) * ROWB <= 80 * 1024 ? 1 : (MT > 2 ? 1 : MT);
-  if (p.y_fmt && p.split == p.Cout) epilogue_sh32<MT, NT, EIB>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
-  else if (p.vec_epi) epilogue_vec<MT, NT, EIB>(acc, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
-  else epilogue_scalar<MT, NT>(acc, p, m0 + wm * TM, n0 + wn * TN, lane);
+  if constexpr (FOLD) fold();            // the last (possibly shorter) slice; a no-op sum of zeros when the step count divides evenly
+  const f32x16 (&fin)[MT][NT] = FOLD ? tot : acc;
+  if (p.y_fmt && p.split == p.Cout) epilogue_sh32<MT, NT, EIB>(fin, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
+  else if (p.vec_epi) epilogue_vec<MT, NT, EIB>(fin, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
+  else epilogue_scalar<MT, NT>(fin, p, m0 + wm * TM, n0 + wn * TN, lane);
   if (ABL == 8 && blockIdx.x == 0 && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     reinterpret_cast<long long *>(p.ws)[2] = __builtin_readcyclecounter() - t_start;
@@ -373,6 +394,11 @@ __global__ void pack_weights_dma_kernel(const float *__restrict__ w, unsigned ch
   }
 }
 
+static FILE *shape_log_file() {
+  static FILE *const f = getenv("MIVOS_CONV_LOG") ? fopen(getenv("MIVOS_CONV_LOG"), "a") : nullptr;
+  return f;
+}
+
 template <int BM, int BN, int WGM, int WGN, int ABL = 0>
 static int launch_pp(ConvP &p, hipStream_t st) {
   const int tiles_m = cdiv(p.M, BM);
@@ -384,14 +410,19 @@ static int launch_pp(ConvP &p, hipStream_t st) {
   const long long x_bytes = ((long long)(p.N - 1) * p.x_ns + (long long)(p.H + 2 * p.pad - 1) * p.x_rs + (long long)(p.W + 2 * p.pad) * p.x_ps) * 4;
   const long long w_bytes = ROWB + (long long)(p.Cin >> 5) * p.KH * p.KW * p.Cout * ROWB;
   if (x_bytes >= 0x7ff00000ll || w_bytes >= 0x7ff00000ll) return fail(MIVOS_ERR_INVALID_ARGUMENT, "conv2d (SH32 input): tensor larger than 2 GB");
-  // split-K when the tile grid cannot fill the chip and K is long (30x54 layers at small batch)
-  static const int share_cap = getenv("MIVOS_PP_SHARE_CAP") ? atoi(getenv("MIVOS_PP_SHARE_CAP")) : 1;   // tuning only: 0 = ignore chip_share
-  const int nk = (p.Cin >> 5) * p.KH * p.KW, wgs = tiles_m * p.tiles_n, cap = (lds <= 80 * 1024 ? 512 : 256) / (share_cap && p.share > 1 ? p.share : 1);
+  // Split-K: ONLY for grids that leave three quarters of the workgroup slots empty and have enough K steps to amortise the partial-sum round trip.
+  // The rule looks at the layer shape alone - never at mivos_conv_desc.chip_share - because the number of K slices is the fp32 summation order: with a
+  // share-dependent rule (round 5) the masks of a clip changed with the number of clips in flight.  Measured per shape IN SITU (rocprofv3 kernel trace of a
+  // config-3 session joined with the launch log, profiles/r06b_insitu_*): at M = 8100 the 3x3 256->256 layers (128 workgroups, 72 K steps) take 42 us split by 4
+  // (reduce included) against 61 us unsplit; the 1x1 1024->256 layers (32 steps) 34.8 vs 34.6, the decoder's 512->512 layers (256 workgroups) 222 vs 220,
+  // KeyValue (320) 275 vs 283 - those no longer split (less partial-sum traffic, 9 fewer reduce launches per frame, and nothing a second clip's launches
+  // would have to queue behind).
+  static const int split_on = getenv("MIVOS_PP_SPLIT_THR") ? atoi(getenv("MIVOS_PP_SPLIT_THR")) : 1;   // tuning only: 0 = never split
+  static const int min_nk = getenv("MIVOS_PP_SPLIT_MIN_NK") ? atoi(getenv("MIVOS_PP_SPLIT_MIN_NK")) : 64;   // tuning only
+  const int nk = (p.Cin >> 5) * p.KH * p.KW, wgs = tiles_m * p.tiles_n, cap = lds <= 80 * 1024 ? 512 : 256;
   int slices = 1;
-  static const int thr6 = getenv("MIVOS_PP_SPLIT_THR") ? atoi(getenv("MIVOS_PP_SPLIT_THR")) : 4;   // tuning only: split when fewer than thr6/6 of the workgroup slots are filled (A/B: +0.7 % end to end vs 2)
-  static const int long_nk = getenv("MIVOS_PP_SPLIT_LONG_NK") ? atoi(getenv("MIVOS_PP_SPLIT_LONG_NK")) : 96;   // tuning only: K steps from which a grid that fills > 1/3 of the slots is still split
-  if (p.vec_epi && p.ws && wgs * 6 <= cap * thr6 && nk >= (wgs * 3 <= cap ? 16 : long_nk)) {   // nearly full grids: only very long K
-    slices = cap / wgs < 2 ? 2 : cap / wgs;
+  if (split_on && p.vec_epi && p.ws && wgs * 4 <= cap && nk >= (wgs >= 64 ? min_nk : 16)) {
+    slices = cap / wgs;
     if (slices > 8) slices = 8;
     if (slices > nk / 8) slices = nk / 8;
     if ((long long)slices * p.M * p.Cout * 4 > p.ws_bytes) slices = 1;
@@ -400,8 +431,22 @@ static int launch_pp(ConvP &p, hipStream_t st) {
   if (force_slices && p.vec_epi && p.ws && (long long)force_slices * p.M * p.Cout * 4 <= p.ws_bytes && nk >= 2 * force_slices) slices = force_slices;
   p.kt_split = 0;
   if (slices > 1) { p.kt_split = cdiv(nk, slices); slices = cdiv(nk, p.kt_split); p.partial = (float *)p.ws; }
+  // The caller keeps other launch streams busy (chip_share > 1): the same K slices, folded inside one workgroup each (see FOLD above) - identical bits, no
+  // partial sums, no reduce launch.  Tiles up to 128x128 only (the accumulators of the total must fit the register file); MIVOS_PP_FOLD=0 never folds,
+  // =2 folds every split layer whatever the hint (A/B, tests).
+  static const int fold_mode = getenv("MIVOS_PP_FOLD") ? atoi(getenv("MIVOS_PP_FOLD")) : 1;
+  if constexpr (ABL == 0 && BM * BN <= 128 * 128) {
+    if (slices > 1 && (fold_mode == 2 || (fold_mode == 1 && p.share > 1))) {
+      auto kfold = conv_f16x3_pp_kernel<BM, BN, WGM, WGN, 0, true>;
+      static std::atomic<uint64_t> fold_attr_mask{0};
+      if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kfold), lds, fold_attr_mask, "conv_f16x3_pp (folded)")) return rc;
+      if (shape_log_file()) { fprintf(shape_log_file(), "pp %d %d %d %d %d %d %d %d %d %d %d %d\n", BM, BN, p.M, p.Cin, p.Cout, p.KH, p.stride, p.res ? 1 : 0, -slices, tiles_m * p.tiles_n, p.share, p.y_fmt); fflush(shape_log_file()); }
+      hipLaunchKernelGGL(kfold, dim3(tiles_m * p.tiles_n, 1), dim3(512), lds, st, p, (unsigned)x_bytes, (unsigned)w_bytes);
+      return check_launch("conv_f16x3_pp (folded)");
+    }
+  }
   // profiling only (scripts/insitu_shape_table.py): one line per launch, in host order, to join with a rocprofv3 kernel trace by dispatch order
-  static FILE *const shape_log = getenv("MIVOS_CONV_LOG") ? fopen(getenv("MIVOS_CONV_LOG"), "a") : nullptr;
+  FILE *const shape_log = shape_log_file();
   if (shape_log) {
     fprintf(shape_log, "pp %d %d %d %d %d %d %d %d %d %d %d %d\n", BM, BN, p.M, p.Cin, p.Cout, p.KH, p.stride, p.res ? 1 : 0, slices, tiles_m * p.tiles_n, p.share, p.y_fmt);
     fflush(shape_log);

@@ -1539,26 +1539,27 @@ static void launch_finalize_n(void *workspace, const float *values, int64_t valu
 // count instead of the largest any of the three kernels could have produced (480p, 5 objects: 4 entries per lane instead of
 // 15 - the 256-query plan that never runs there cuts a stream into 9 segments).  Registers, not time: the launch is bound by
 // its value gather (810 MB of rows per launch at 480p, 5 objects; 82 vs 84 us, profiles/r03h_config3_kernel_stats*.csv).
+struct WsPlan { int qt, slots; };
 static std::mutex g_ws_mutex;
-static std::unordered_map<const void *, int> g_ws_qt;
+static std::unordered_map<const void *, WsPlan> g_ws_qt;
 // Bounded: callers reallocate their workspace when the bank grows, so stale addresses accumulate in a long-lived process; when
 // the table is full it is dropped (finalize then sizes for the largest plan - the documented fallback, 84 vs 82 us).  An entry
 // exists only while the LAST select launch on that workspace succeeded: launch_select erases it first and records it after the
 // launch was accepted, so a failed select can never leave a plan that did not write the header.
 static const size_t WS_PLAN_ENTRIES = 256;
-static void remember_select_plan(const void *workspace, int qt) {
+static void remember_select_plan(const void *workspace, int qt, int slots) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   if (g_ws_qt.size() >= WS_PLAN_ENTRIES && !g_ws_qt.count(workspace)) g_ws_qt.clear();
-  g_ws_qt[workspace] = qt;
+  g_ws_qt[workspace] = WsPlan{qt, slots};
 }
 static void forget_select_plan(const void *workspace) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   g_ws_qt.erase(workspace);
 }
-static int recall_select_plan(const void *workspace) {
+static WsPlan recall_select_plan(const void *workspace) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   const auto it = g_ws_qt.find(workspace);
-  return it == g_ws_qt.end() ? 0 : it->second;
+  return it == g_ws_qt.end() ? WsPlan{0, 0} : it->second;
 }
 
 // The kernel reads the plan from the workspace header; the host only picks how many merged candidates a lane may hold: for the
@@ -1569,8 +1570,11 @@ static int launch_finalize(bool indices, void *workspace, const float *values, i
                            hipStream_t st, const ShOut &sh = ShOut{nullptr, nullptr, 0, 0, 0, 1}) {
   const Plan p64 = make_plan(n_obj, n_mem, n_q, top_k, QT);
   int slots;
-  if (const int qt = recall_select_plan(workspace)) {
-    slots = make_plan(n_obj, n_mem, n_q, top_k, qt).slots;
+  const WsPlan seen = recall_select_plan(workspace);
+  if (seen.qt) {
+    // the slot count the select launch on this workspace actually used (remembered with its plan): mivos_memory_read_set_workgroups may have
+    // changed the workgroup count since - a plan recomputed here could be smaller than what the header in the workspace describes
+    slots = seen.slots;
   } else {
     const Plan p128 = make_plan(n_obj, n_mem, n_q, top_k, QT2), p256 = make_plan(n_obj, n_mem, n_q, top_k, QT3);
     slots = p64.slots > p128.slots ? p64.slots : p128.slots;
@@ -1702,7 +1706,7 @@ static int launch_select(bool f16, const float *keys, int64_t keys_ostride, cons
             qt == QT2 ? 24 * 32 : (f16 ? 24 * 17 : 64 * 32), h[3], h[2], h[5], h[4]);
   }
   if (int rc = check_launch("memread_select")) return rc;
-  remember_select_plan(workspace, qt);
+  remember_select_plan(workspace, qt, pl.slots);
   return MIVOS_OK;
 }
 

@@ -50,8 +50,14 @@ class DAVISProcessor:
             # ki = cat([frame, current mask of object ki (hard: S2M is trained with such), its positive / negative scribbles])
             cur_k = (cur[None] == ids.view(K, 1, 1, 1)).float()                      # [K,1,nh,nw]
             inputs = torch.cat([frame.expand(K, -1, -1, -1), cur_k, rs[0].unsqueeze(1), rs[1].unsqueeze(1)], 1)
-            mask = ops.sigmoid(self.s2m_net(inputs))
-            return aggregate_wbg(mask, keep_bg=True, hard=True)
+            if getattr(self, "_s2m_range", None) is None:
+                self._s2m_range = ops.new_range_status(self.device)
+            with ops.range_status(self._s2m_range):                                  # the S2M convolutions' fp16-range flag: this processor's own word
+                mask = ops.sigmoid(self.s2m_net(inputs))
+            out = aggregate_wbg(mask, keep_bg=True, hard=True)
+            if ops.CONV_PRECISION == "f16x3":
+                ops.check_activation_range(self._s2m_range)                          # (one 4-byte read per interaction)
+            return out
 
     def to_mask(self, scribble):
         """The reference's entry point: a DAVIS scribble dict (davis_processor.py:38-50)."""

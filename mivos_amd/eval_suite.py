@@ -56,7 +56,7 @@ def run_suite(specs, engine_factory, rank=0, world=1, sync=None, on_clip=None, l
     lane i inside the context `lane_ctx(i)` - a HIP stream per lane (`stream_lanes`), so that the under-filled launches of one
     clip (a 480p frame of 1-5 objects fills a fraction of the 256 CUs at the 1/16-resolution layers) run beside the other's.
     Clips stay independent - no tensor is shared between lanes but the read-only weights - and the results are bit-identical
-    to lanes = 1 run with the same launch-geometry hint (ops.chip_share; tests), i.e. equal up to the fp32 summation order of split-K.  A clip's `seconds` is then its share of the rank's wall clock (its own in-flight time, scaled so
+    to a lanes = 1 run (tests; since round 6 the launch-geometry hint ops.chip_share no longer enters the split-K slicing).  A clip's `seconds` is then its share of the rank's wall clock (its own in-flight time, scaled so
     that the clips of a rank add up to the rank's wall clock), which keeps `summarize` and the cost-model fit meaningful."""
     parts = shard.assign_sequences([shard.clip_cost(s.frames - 1, s.objects) for s in specs], world)
     if lanes <= 1:
@@ -120,12 +120,18 @@ def _advance_lanes(specs, engine_factory, rank, lanes, lane_ctx, on_clip, todo, 
                     del active[lane]
 
 
+_LANE_STREAMS = {}
+
+
 def stream_lanes(device, lanes):
     """`lane_ctx` of run_suite for a GPU: one HIP stream per lane (created once), entered with torch.cuda.stream; its `chip_share`
     attribute (ops.chip_share) tells every convolution launched inside how many streams share the chip."""
     import torch
     from . import ops
-    streams = [torch.cuda.Stream(device=device) for _ in range(lanes)]
+    key = (str(device), lanes)
+    if key not in _LANE_STREAMS:                # once per process: the allocator pools and per-stream workspaces stay warm from suite to suite
+        _LANE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(lanes)]
+    streams = _LANE_STREAMS[key]
 
     def ctx(lane):
         return torch.cuda.stream(streams[lane])

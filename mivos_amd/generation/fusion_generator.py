@@ -41,6 +41,7 @@ class FusionGenerator:
         self.query_buf = {}
         self.propagated_frames = 0
         self._pass_stream = None
+        self._range = ops.new_range_status(self.device)      # this generator's fp16-range flag (ops.range_status)
 
     def reset(self, k):
         self.k = k
@@ -112,7 +113,7 @@ class FusionGenerator:
             return
         main = torch.cuda.current_stream()
         if self._pass_stream is None:
-            self._pass_stream = torch.cuda.Stream(device=self.device)
+            self._pass_stream = ops.side_stream(self.device, "pass")
         side = self._pass_stream
         side.wait_stream(main)
         for t in (key_k, key_v):
@@ -131,11 +132,15 @@ class FusionGenerator:
         """mask [K,1,H,W]: the objects' masks of frame idx (generate_fusion.py:104) -> probabilities [K+1, T, H, W] of the frames
         left_limit .. right_limit (the others keep reset()'s zeros)."""
         with ops.on_device(self.device), torch.no_grad():
-            mask = mask.to(self.device).float()
-            mask, _ = pad_divide_by(mask, 16, mask.shape[-2:])
-            mask = aggregate_wbg(mask.contiguous(), keep_bg=True)
-            self.prob[:, idx] = mask
-            key_k, key_v = self.prop_net.memorize_into(self.get_im(idx), mask[1:])
-            self._run_passes(key_k, key_v, idx, left_limit, right_limit)
+            self._range.zero_()
+            with ops.range_status(self._range):               # (no yield leaves this function: the passes' generators are advanced inside it)
+                mask = mask.to(self.device).float()
+                mask, _ = pad_divide_by(mask, 16, mask.shape[-2:])
+                mask = aggregate_wbg(mask.contiguous(), keep_bg=True)
+                self.prob[:, idx] = mask
+                key_k, key_v = self.prop_net.memorize_into(self.get_im(idx), mask[1:])
+                self._run_passes(key_k, key_v, idx, left_limit, right_limit)
+            if ops.CONV_PRECISION == "f16x3":                 # an overflow inside the network must not be silent here either (one 4-byte read per call)
+                ops.check_activation_range(self._range)
             l, r, t, b = self.pad
             return self.prob[:, :, 0, t:self.nh - b, l:self.nw - r]

@@ -129,6 +129,7 @@ class InferenceCore:
         self._certain_k = self._certain_v = None     # [K, n, h, w, C] rows per memory position
         self.propagated_frames = 0                   # do_pass iterations so far (the bench metric)
         self._fuse_stream = self._pass_stream = None
+        self._range = ops.new_range_status(self.device)      # this core's fp16-range flag (ops.range_status): raised by ITS launches, read by it alone
 
     # ---- reference-shaped views of the certain memory -------------------------------------
     @property
@@ -200,11 +201,12 @@ class InferenceCore:
     # fusion launches therefore go to a second HIP stream behind an event and run beside the next memorize / decode launches:
     # FusionNet is HBM-bound, the encoder GEMMs are matrix-core bound.  Same kernels, same arithmetic, same results.
     FUSE_ON_SIDE_STREAM = os.environ.get("MIVOS_FUSE_SIDE_STREAM", "1") != "0"
+    FUSE_BESIDE_MEMORIZE = os.environ.get("MIVOS_FUSE_BESIDE_MEMORIZE", "0") != "0"      # A/B (round 6): where the side stream's start event is recorded
 
     def _fuse_async(self, closest, idx, ti, out, key_k, q, pending):
         main = torch.cuda.current_stream()
         if self._fuse_stream is None:
-            self._fuse_stream = torch.cuda.Stream(device=self.device)
+            self._fuse_stream = ops.side_stream(self.device, "fuse")      # shared by the cores that run under this stream (warm allocator pool, workspaces)
         side = self._fuse_stream
         ready = torch.cuda.Event()
         ready.record(main)
@@ -241,22 +243,30 @@ class InferenceCore:
         hw = kh * kw
         pending = []
         for si, st in enumerate(steps):
-            q = self._query(st.ti, upcoming=[s2.ti for s2 in steps[si + 1:si + self.QUERY_BATCH]])
-            prob_k = self.prop_net.segment(keys[:, :st.n_read].reshape(K, st.n_read * hw, CK),
-                                           values[:, :st.n_read].reshape(K, st.n_read * hw, CV), q,
-                                           keys_split=None if ksplit is None else ksplit[:, :st.n_read].reshape(K, st.n_read * hw, CK))
-            out = ops.aggregate(prob_k.unsqueeze(1), keep_bg=True)            # [K+1,1,nh,nw]
-            if st.slot is not None:
-                self.prop_net.memorize_into(self.get_image_buffered(st.ti), out[1:],
-                                            key_out=keys[:, st.slot], val_out=values[:, st.slot])
-                if ksplit is not None:
-                    ops.split_keys(keys[:, st.slot], ksplit[:, st.slot])
-            if st.fuse and self.FUSE_ON_SIDE_STREAM and self.result_dev == self.device:
-                self._fuse_async(closest, idx, st.ti, out, key_k, q, pending)
-            else:
-                if st.fuse:
-                    out = self.fuse_one_frame(closest, idx, st.ti, self.prob[:, st.ti], out, key_k, q.k16)
-                self.prob[:, st.ti] = out.to(self.result_dev)
+            with ops.range_status(self._range):              # (per step: never held across the yield)
+                q = self._query(st.ti, upcoming=[s2.ti for s2 in steps[si + 1:si + self.QUERY_BATCH]])
+                prob_k = self.prop_net.segment(keys[:, :st.n_read].reshape(K, st.n_read * hw, CK),
+                                               values[:, :st.n_read].reshape(K, st.n_read * hw, CV), q,
+                                               keys_split=None if ksplit is None else ksplit[:, :st.n_read].reshape(K, st.n_read * hw, CK))
+                out = ops.aggregate(prob_k.unsqueeze(1), keep_bg=True)            # [K+1,1,nh,nw]
+                side_fuse = st.fuse and self.FUSE_ON_SIDE_STREAM and self.result_dev == self.device
+                if side_fuse and self.FUSE_BESIDE_MEMORIZE:
+                    # enqueued BEFORE memorize: the side stream's start event then sits right behind `aggregate`, and the fusion kernels run beside
+                    # this frame's memory encoder (under-filled 30 x 54 layers) instead of beside the NEXT frame's read + decoder
+                    self._fuse_async(closest, idx, st.ti, out, key_k, q, pending)
+                if st.slot is not None:
+                    self.prop_net.memorize_into(self.get_image_buffered(st.ti), out[1:],
+                                                key_out=keys[:, st.slot], val_out=values[:, st.slot])
+                    if ksplit is not None:
+                        ops.split_keys(keys[:, st.slot], ksplit[:, st.slot])
+                if side_fuse and self.FUSE_BESIDE_MEMORIZE:
+                    pass
+                elif side_fuse:
+                    self._fuse_async(closest, idx, st.ti, out, key_k, q, pending)
+                else:
+                    if st.fuse:
+                        out = self.fuse_one_frame(closest, idx, st.ti, self.prob[:, st.ti], out, key_k, q.k16)
+                    self.prob[:, st.ti] = out.to(self.result_dev)
             self.propagated_frames += 1
             if step_cb is not None:
                 step_cb()
@@ -272,7 +282,8 @@ class InferenceCore:
 
     # The forward and the backward pass of an interaction never exchange data (reference inference_core.py:255-256: two do_pass calls
     # over disjoint frame ranges that only READ the certain memory): with everything resident in HBM they advance in turn, frame
-    # by frame, on two HIP streams.  Same kernels, same inputs, same results; MIVOS_CONCURRENT_PASSES=0 runs them one after the other.
+    # by frame, on two HIP streams.  Same kernels, same inputs, bit-identical results (round 6: the split-K slicing of the convolutions no
+    # longer depends on how many streams share the chip); MIVOS_CONCURRENT_PASSES=0 runs them one after the other.
     CONCURRENT_PASSES = os.environ.get("MIVOS_CONCURRENT_PASSES", "1") != "0"
     PASS_CHIP_SHARE = 2     # what the convolutions are told while the two passes are in flight (mivos_conv_desc.chip_share: launch geometry)
 
@@ -289,7 +300,7 @@ class InferenceCore:
             return
         main = torch.cuda.current_stream()
         if self._pass_stream is None:
-            self._pass_stream = torch.cuda.Stream(device=self.device)
+            self._pass_stream = ops.side_stream(self.device, "pass")
         side = self._pass_stream
         side.wait_stream(main)                                   # the interacted frame's keys / values / difference maps
         lanes = [(main, self._pass_steps(plans[0], rows, key_v, idx, step_cb=step_cb)),
@@ -346,6 +357,7 @@ class InferenceCore:
         """Everything of `interact` before the passes (reference :219-253): register the frame, difference maps against the previous
         result, memorise the interacted frame into the certain memory.  Returns (key rows [K, h*w, 128], values) of that frame."""
         self.interacted.add(idx)
+        self._range.zero_()                                   # a flag left by an interaction that aborted must not fail this one
         mask = mask.to(self.device).float()
         mask, _ = pad_divide_by(mask, 16, mask.shape[-2:])
         mask = mask.contiguous()
@@ -353,7 +365,8 @@ class InferenceCore:
         self._prepare_diff(mask, self.prob[:, idx].to(self.device))
         self.prob[:, idx] = mask.to(self.result_dev)
 
-        key_k, key_v = self.prop_net.memorize_into(self.get_image_buffered(idx), mask[1:])   # [K,h,w,C]
+        with ops.range_status(self._range):
+            key_k, key_v = self.prop_net.memorize_into(self.get_image_buffered(idx), mask[1:])   # [K,h,w,C]
         key_k5, key_v5 = key_k.unsqueeze(1), key_v.unsqueeze(1)
         if self._certain_k is None:
             self._certain_k, self._certain_v = key_k5, key_v5
@@ -381,13 +394,23 @@ class InferenceCore:
         and nothing waited for; when it is exhausted the result is in `np_masks` (and is the StopIteration value).  A driver that
         advances the generators of several cores in turn, each under its own stream (eval_suite.run_suite(lanes=2)), overlaps
         their launches on the chip.  The two passes of one interaction run one after the other here."""
+        # (the core's device is made current PER STEP, never across a yield: interleaved generators of cores on different devices would
+        # otherwise restore each other's "previous" device)
         with torch.cuda.device(self.device):
             rows, key_v = self._begin_interaction(mask, idx, total_cb)
             nc = self._certain_k.shape[1]
-            for fwd in (True, False):
-                plan = plan_pass(self.t, self.interacted, idx, fwd, self.mem_freq, nc)
-                if plan[2]:
-                    yield from self._pass_steps(plan, rows, key_v, idx, step_cb=step_cb)
+        for fwd in (True, False):
+            plan = plan_pass(self.t, self.interacted, idx, fwd, self.mem_freq, nc)
+            if not plan[2]:
+                continue
+            steps = self._pass_steps(plan, rows, key_v, idx, step_cb=step_cb)
+            while True:
+                with torch.cuda.device(self.device):
+                    ti = next(steps, None)
+                if ti is None:
+                    break
+                yield ti
+        with torch.cuda.device(self.device):
             return self._refresh_masks()
 
     REFRESH_CHUNK_BYTES = 1 << 30     # host-resident results (mem_profile 2/3): probabilities visit the GPU in chunks
@@ -405,14 +428,26 @@ class InferenceCore:
         # flag read below.)
         out = self._argmax_and_copy(l, r, t, b, P)
         if ops.CONV_PRECISION == "f16x3":          # the epilogues' fp16-range guard (round 5): an overflow INSIDE the network is no longer silent
-            ops.check_activation_range(self.device)
+            ops.check_activation_range(self._range)  # (this core's own word: the passes' streams were joined into the current one)
         return out
+
+    @staticmethod
+    def _to_host_u8(view):
+        """uint8 device view [T, h, w] -> a numpy array of its own (the interaction's result, 29 MB for 70 frames of 480p): cropped into a dense
+        tensor on the GPU, ONE copy into page-locked host memory (torch's caching host allocator: the block is recycled once the array is dropped),
+        one stream synchronisation.  The pageable `.cpu().numpy().astype(uint8)` of rounds 1-5 cost two more host-side passes over the array
+        (~5 ms per interaction with the GPU idle)."""
+        dense = view.contiguous()
+        host = torch.empty(dense.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(dense, non_blocking=True)
+        torch.cuda.current_stream(dense.device).synchronize()
+        return host.numpy()
 
     def _argmax_and_copy(self, l, r, t, b, P):
         if self.prob.device == self.device:
             m = ops.argmax_u8(self.prob.view(self.k + 1, self.t * P)).view(self.t, 1, self.nh, self.nw)
             self.masks = m
-            self.np_masks = m[:, 0, t:self.nh - b, l:self.nw - r].cpu().numpy().astype(np.uint8)
+            self.np_masks = self._to_host_u8(m[:, 0, t:self.nh - b, l:self.nw - r])
             return self.np_masks
         step = max(1, self.REFRESH_CHUNK_BYTES // ((self.k + 1) * P * 4))
         for t0 in range(0, self.t, step):

@@ -73,7 +73,9 @@ def single_stream_region():
 
 @contextlib.contextmanager
 def chip_share(n):
-    """Inside: convolutions are told that `n` independent launch streams share this GPU (CHIP_SHARE -> mivos_conv_desc.chip_share)."""
+    """Inside: the kernels are told that `n` independent launch streams share this GPU: the persistent select kernels leave the other streams their
+    share of the CUs (CUs / n workgroups).  Results are bit-identical for every n (tests/test_gpu_engine.py::test_concurrent_passes_and_suite_lanes_are_bit_identical).
+    Process-wide state, set from the one host thread that drives the lanes; not thread-safe."""
     global CHIP_SHARE
     old, CHIP_SHARE = CHIP_SHARE, max(1, int(n))
     lib, old_wgs = None, 0
@@ -87,6 +89,22 @@ def chip_share(n):
         CHIP_SHARE = old
         if lib is not None:
             lib.mivos_memory_read_set_workgroups(old_wgs)
+
+
+_side_streams = {}
+
+
+def side_stream(device, purpose):
+    """The side HIP stream `purpose` ("fuse", "pass", ...) of the CURRENT stream on `device`, created once per process and reused by every core /
+    generator that works under that stream.  A fresh torch.cuda.Stream per InferenceCore (rounds 3-5) meant a fresh allocator pool and fresh
+    per-stream workspaces / scratch for every clip: ~30 ms of hipMalloc with the GPU idle at the first fused frame of every session (rocprofv3
+    timeline, profiles/r06a_*) and workspaces that were never released (48 GB allocated after two 480p sessions)."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream, purpose)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 def publish_constants():
@@ -271,7 +289,8 @@ import collections
 _act_scratch = collections.OrderedDict()
 ACT_SCRATCH_ENTRIES = 256   # scratch buffers kept per process (least recently used ones go first)
 CHIP_SHARE = 1          # independent launch streams the caller keeps busy on this GPU (lanes of run_suite / bench, the two passes of an interaction):
-                        # passed to every convolution as mivos_conv_desc.chip_share (launch-geometry hint: split-K slicing, i.e. results equal up to the fp32 summation order)
+                        # the persistent select kernels take CUs / CHIP_SHARE workgroups (exact selection: same results); also passed to every convolution as
+                        # mivos_conv_desc.chip_share, which since round 6 does not enter any decision that changes the arithmetic (results are bit-identical for every value)
 COUT1_PROJECTION = True # one-output-channel 3x3 layers as a 1x1 projection to nine tap products + tap_sum9 (False: the generic kernels; diagnostics)
 USE_ACT_PATH = True     # run conv -> conv edges on the LDS-DMA kernels (needs CONV_PRECISION == "f16x3")
 
@@ -412,7 +431,8 @@ def conv(x, L, relu_in=False, relu_out=False, res=None, out=None, out2=None, out
         d.res_nstride, d.res_pstride = (0 if (res.shape[0] == 1 and n > 1) else rn), rp
     ws = _workspace(SPLITK_WORKSPACE_BYTES, dev)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() - STATUS_BYTES
-    d.status = ws.data_ptr() + ws.numel() - STATUS_BYTES          # fp16-range guard of the f16x3 epilogues (check_activation_range)
+    # fp16-range guard of the f16x3 epilogues (check_activation_range): the owner's word, else the tail of this stream's workspace
+    d.status = RANGE_STATUS.data_ptr() if (RANGE_STATUS is not None and RANGE_STATUS.device == dev) else ws.data_ptr() + ws.numel() - STATUS_BYTES
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -655,22 +675,50 @@ def _workspace(nbytes, device, purpose="splitk"):
     return ws
 
 
-def check_activation_range(device):
-    """Raise MivosHipError if any f16x3 convolution launched on `device` since the last check produced an output beyond the fp16 range
-    (|y| > 65504: the next layer's hi / lo operand split would turn it into inf, and the ReLUs / `aggregate_wbg`'s clamp downstream would
-    turn the NaNs that follow into finite numbers - silently).  The epilogues raise a status word in the tail of their stream's split-K
-    workspace (mivos_conv_desc.status); this reads those words (one 4-byte copy per stream that launched convolutions) and clears them.
-    InferenceCore calls it once per interaction, next to the mask download it waits for anyway.  Covers the convolution epilogues (trunks,
-    KeyValue, decoder) - the stems, FusionNet's own kernels and the pointwise kernels are not instrumented (INTEGRATION.md "Limits")."""
-    device = torch.device(device)
+RANGE_STATUS = None     # int32 device tensor (>= 1 word) in which the f16x3 convolution epilogues launched from now on raise their fp16-range flag
+                        # (mivos_conv_desc.status); None: the tail of the launching stream's split-K workspace.  Owners (InferenceCore, FusionGenerator,
+                        # the S2M network) point it at THEIR OWN word for the duration of a step (range_status) and check that word only, so that
+                        # several cores in flight (lanes) never read or clear each other's evidence.
+
+
+def new_range_status(device):
+    return torch.zeros(STATUS_BYTES // 4, dtype=torch.int32, device=device)
+
+
+@contextlib.contextmanager
+def range_status(word):
+    """Inside: convolutions raise their fp16-range flag in `word` (see RANGE_STATUS).  Not to be held across a generator's yield."""
+    global RANGE_STATUS
+    old, RANGE_STATUS = RANGE_STATUS, word
+    try:
+        yield
+    finally:
+        RANGE_STATUS = old
+
+
+def check_activation_range(target):
+    """Raise MivosHipError if an f16x3 convolution produced an output beyond the fp16 range (|y| > 65504: the next layer's hi / lo operand split
+    would turn it into inf, and the ReLUs / `aggregate_wbg`'s clamp downstream would turn the NaNs that follow into finite numbers - silently).
+    `target`: the status tensor an owner passed to `range_status` for its launches (new_range_status; read with one 4-byte copy on the current
+    stream - the caller's launches must be on it or joined into it - and cleared) or, for code that launched convolutions outside any
+    `range_status` region, a device: then the tails of that device's split-K workspaces are swept (every stream's; ordered only against the
+    current stream).  InferenceCore checks its own word once per interaction, next to the mask download it waits for anyway.  Covers the
+    convolution epilogues (trunks, KeyValue, decoder, S2M) - the stems, FusionNet's own kernels and the pointwise kernels are not instrumented
+    (INTEGRATION.md "Limits")."""
     bad = False
-    for (purpose, index, _stream_id), ws in list(_ws_cache.items()):
-        if purpose != "splitk" or index != device.index:
-            continue
-        word = ws[-STATUS_BYTES:-STATUS_BYTES + 4].view(torch.int32)
-        if int(word.item()) != 0:
+    if isinstance(target, torch.Tensor):
+        if int(target[0].item()) != 0:
             bad = True
-            word.zero_()
+            target.zero_()
+    else:
+        device = torch.device(target)
+        for (purpose, index, _stream_id), ws in list(_ws_cache.items()):
+            if purpose != "splitk" or index != device.index:
+                continue
+            word = ws[-STATUS_BYTES:-STATUS_BYTES + 4].view(torch.int32)
+            if int(word.item()) != 0:
+                bad = True
+                word.zero_()
     if bad:
         raise MivosHipError("an activation left the fp16 range (|y| > 65504) inside an f16x3 convolution: the default precision carries operands as fp16 hi + lo "
                             "pairs (INTEGRATION.md 'Limits').  Results of this interaction are invalid; use ops.CONV_PRECISION = 'f32' for these weights.")

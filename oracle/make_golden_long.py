@@ -6,8 +6,8 @@ fixture conditioning was NOT tuned on.
 TEST INFRASTRUCTURE ONLY (this container: /root/reference does not exist on the GPU box).  Writes tests/golden/long_s<seed>_k<K>.npz:
 
   masks32_<n>     uint8 [T, H, W]      the reference's masks after interaction n (full resolution: IoU is exact)
-  masks64_<n>     uint8 [T, H, W]      the fp64 run's masks
-  frames          int   [F]            frames whose probabilities are kept (every FRAME_STEP-th + both ends)
+  x64_<n>         uint8 [T, H, W]      masks32 XOR the fp64 run's masks (a few hundred non-zero pixels per frame: compresses to nothing)
+  frames          int   [F]            frames whose probabilities are kept (every FRAME_STEP-th + the last)
   p64_<n>         f32   [K+1, F, h/SUB, w/SUB]   fp64 run's probabilities at every SUB-th pixel in both directions of the PADDED frame
   d32_<n>         f16   [K+1, F, h/SUB, w/SUB]   (reference fp32 - fp64) at the same samples (|d| ~ 1e-4: fp16 keeps it to 1e-7 absolute)
   admission_<n>   f64   [T]            IoU of the reference's fp32 masks against the fp64 run's, per frame (NaN at not-yet-propagated frames)
@@ -34,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 SUB = 8            # probability samples: every SUB-th pixel in both directions
-FRAME_STEP = 5     # ... of every FRAME_STEP-th frame (plus the last frame)
+FRAME_STEP = 10    # ... of every FRAME_STEP-th frame (plus the last frame)
 ADMISSION_BAR = 0.9995
 
 
@@ -59,18 +59,54 @@ def kept_frames(t):
     return np.asarray(f, dtype=np.int64)
 
 
+def pack(out):
+    """The committed form of a session record: fp64 masks as XOR against the reference's, probabilities of every FRAME_STEP-th frame only
+    (a K = 5 session is then ~11 MB instead of 24; the masks of an untrained network have noisy boundaries and do not compress further)."""
+    frames = np.asarray(out["frames"])
+    keep = np.asarray([i for i, t in enumerate(frames) if t % FRAME_STEP == 0 or i == len(frames) - 1])
+    res = {}
+    for k, v in out.items():
+        if k.startswith("masks64_"):
+            res["x64_" + k[8:]] = v ^ out["masks32_" + k[8:]]
+        elif k.startswith("p64_") or k.startswith("d32_"):
+            res[k] = np.ascontiguousarray(v[:, keep])
+        elif k == "frames":
+            res[k] = frames[keep]
+        else:
+            res[k] = v
+    return res
+
+
+def load(path):
+    """A committed fixture as a dict with masks64_<n> restored."""
+    z = np.load(path)
+    d = {k: z[k] for k in z.files}
+    for k in list(d):
+        if k.startswith("x64_"):
+            d["masks64_" + k[4:]] = d["masks32_" + k[4:]] ^ d.pop(k)
+    return d
+
+
 def golden_path(seed, objects):
     return os.path.join(ROOT, "tests", "golden", f"long_s{seed}_k{objects}.npz")
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--seed", type=int, required=True)
-    ap.add_argument("--objects", type=int, required=True)
+    ap.add_argument("--repack", default=None, help="rewrite an .npz written in the unpacked form (masks64_<n>, every 5th frame) in the committed form")
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--objects", type=int, default=None)
     ap.add_argument("--frames", type=int, default=70)
     ap.add_argument("--threads", type=int, default=6)
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
+    if args.repack:
+        z = np.load(args.repack)
+        d = {k: z[k] for k in z.files}
+        if "masks64_0" in d:
+            np.savez_compressed(args.repack, **pack(d))
+        print("repacked", args.repack, os.path.getsize(args.repack) >> 10, "KiB")
+        return
     torch.set_grad_enabled(False)
     torch.set_num_threads(args.threads)
     from oracle import ref_loader
@@ -124,7 +160,7 @@ def main():
                torch=torch.__version__, reference="unmodified /root/reference InferenceCore on PyTorch-CPU fp32 (oracle/ref_loader.py)")
     out["config"] = json.dumps(cfg)
     path = args.out or golden_path(args.seed, args.objects)
-    np.savez_compressed(path, **out)
+    np.savez_compressed(path, **pack(out))
     print("wrote", path, os.path.getsize(path) >> 10, "KiB; admitted:", admitted, "worst self IoU", worst, flush=True)
 
 

@@ -50,7 +50,7 @@ def test_config3_two_ranks_stub_engine_weak_scaling_line():
     for d, n in ((two, 2), (one, 1)):
         assert d["n_gpus"] == n and d["scaling"] == "weak" and d["steps"] == 20 and d["warmup"] == 5 and d["stub_engine"] is True
         assert d["config"]["baseline_config"] == 3 and d["config"]["clips_in_flight_per_gpu"] == 1
-        assert d["config"]["untimed_steps_before_warmup"] == 54 and d["config"]["plain_steps"] == 10 and d["config"]["fused_steps"] == 10
+        assert d["config"]["untimed_steps_before_warmup"] == 137 + 54 and d["config"]["plain_steps"] == 10 and d["config"]["fused_steps"] == 10
         assert [r["rank"] for r in d["per_rank"]] == list(range(n)) and all(r["steps"] == 20 for r in d["per_rank"])
         assert d["full_session"]["steps"] == 137 and d["full_session"]["plain"] == 69 and d["full_session"]["fused"] == 68
         assert d["sustained"]["steps"] == 8 * 137 and d["sustained"]["sessions_in_flight"] == 1
@@ -63,7 +63,7 @@ def test_window_phase_places_short_windows_across_the_plain_fused_boundary():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     c3, c2 = bench.CONFIGS[3], bench.CONFIGS[2]
-    assert bench.window_phase(c3, 70, 5, 20) == (54, 10, 10)                 # the driver's flags: steps 59..79 of the session = 10 plain + 10 fused
+    assert bench.window_phase(c3, 70, 5, 20) == (137 + 54, 10, 10)           # the driver's flags: one whole session, then steps 59..79 of the next = 10 plain + 10 fused
     assert bench.window_phase(c3, 70, 137, 8 * 137) == (0, 8 * 69, 8 * 68)   # whole sessions start at the session's start
     assert bench.window_phase(c3, 70, 0, 137) == (0, 69, 68)
     assert bench.window_phase(c2, 70, 5, 20) == (0, 20, 0)                   # one interaction: nothing to straddle
@@ -71,4 +71,4 @@ def test_window_phase_places_short_windows_across_the_plain_fused_boundary():
     assert (pre + 5 + plain) % (2 * 137) == 2 * 69 and plain == 10 and fused == 10
     for w, k in ((0, 1), (3, 7), (50, 60), (100, 30), (136, 136)):
         pre, plain, fused = bench.window_phase(c3, 70, w, k)
-        assert plain + fused == k and 0 <= pre < 137 and abs(plain - k * 69 / 137) <= 1
+        assert plain + fused == k and 137 <= pre < 2 * 137 and abs(plain - k * 69 / 137) <= 1

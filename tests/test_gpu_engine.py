@@ -536,9 +536,8 @@ def test_concurrent_passes_and_suite_lanes_are_bit_identical(nets):
     for conc in (False, True):
         core = InferenceCore(prop, fuse, images, 3, mem_freq=2, device=DEV)
         core.CONCURRENT_PASSES = conc
-        # the concurrent order normally tells the convolutions that two streams share the chip (split-K slicing follows, i.e. the fp32
-        # summation order); here both orders keep the single-stream launch geometry so that the comparison is bit for bit
-        core.PASS_CHIP_SHARE = 1
+        # (round 6: the concurrent order tells the kernels that two streams share the chip - ops.chip_share - and that hint no longer
+        # enters the split-K slicing, so the DEFAULT settings of both orders are compared bit for bit; round 5 had to force PASS_CHIP_SHARE = 1)
         outs = [core.interact(gt[idx], idx).copy() for idx in (0, 10, 5, 7)]        # 5 and 7: both passes exist, both fused
         runs[conc] = (outs, core.prob.clone(), core.propagated_frames)
         assert (core._pass_stream is not None) == conc
@@ -551,11 +550,16 @@ def test_concurrent_passes_and_suite_lanes_are_bit_identical(nets):
     def factory(spec):
         im, g = synthetic.synthetic_clip_device(spec.frames, spec.height, spec.width, spec.objects, seed=spec.seed, device=DEV)
         return InferenceCore(prop, fuse, im, spec.objects, mem_freq=3, device=DEV), g[0]
-    with ops.chip_share(2):                                        # same launch geometry as the two-lane run (see above)
-        one = ES.run_suite(specs, factory, sync=torch.cuda.synchronize)
+    # one clip at a time (no hint), two and three clips in flight (ops.chip_share(2 / 3) inside run_suite): identical mask checksums - a suite's
+    # results must not depend on how many clips happened to be in flight (round 5: three different checksums, profiles/r05c_lanes_ab.txt)
+    one = ES.run_suite(specs, factory, sync=torch.cuda.synchronize)
     two = ES.run_suite(specs, factory, sync=torch.cuda.synchronize, lanes=2, lane_ctx=ES.stream_lanes(DEV, 2))
-    assert [(r["clip"], r["checksum"]) for r in one] == [(r["clip"], r["checksum"]) for r in two]
-    assert all(r["lanes"] == 2 for r in two)
+    three = ES.run_suite(specs, factory, sync=torch.cuda.synchronize, lanes=3, lane_ctx=ES.stream_lanes(DEV, 3))
+    assert [(r["clip"], r["checksum"]) for r in one] == [(r["clip"], r["checksum"]) for r in two] == [(r["clip"], r["checksum"]) for r in three]
+    assert all(r["lanes"] == 2 for r in two) and all(r["lanes"] == 3 for r in three)
+    with ops.chip_share(4):                                         # the hint alone, on one stream: same bits
+        hinted = ES.run_suite(specs, factory, sync=torch.cuda.synchronize)
+    assert [(r["clip"], r["checksum"]) for r in one] == [(r["clip"], r["checksum"]) for r in hinted]
 
 
 def test_interaction_order_and_reinteraction_vs_oracle(nets, synthetic_states):

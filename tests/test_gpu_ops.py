@@ -237,6 +237,54 @@ def test_conv2d_lds_dma_matches_register_staged_kernel_bitwise():
     assert torch.equal(a, b)
 
 
+FOLD_CASES = [
+    # n, cin, cout, k, stride, h, w, relu_out, res ("", "f32", "act"), bn, out_act     -- shapes whose grids split K (<= 1/4 of the workgroup slots)
+    (5, 256, 256, 3, 1, 30, 54, True, "", True, True),          # the M = 8100 bottleneck 3x3 of the memory encoder: 128 workgroups, 72 steps -> 4 slices
+    (5, 256, 256, 3, 2, 60, 108, True, "", True, True),         # its stride-2 sibling
+    (1, 1024, 256, 1, 1, 30, 54, True, "", True, True),         # one frame: 26 workgroups, 32 steps -> 4 slices
+    (1, 512, 256, 3, 1, 30, 54, True, "act", True, True),       # SH32 residual + SH32 output through the folded epilogue (26 workgroups, 144 steps -> 8 slices)
+    (1, 512, 192, 3, 1, 9, 11, True, "act", False, True),       # ragged everything, last slice shorter (144 steps / 8 slices of 18)
+    (1, 512, 200, 3, 1, 9, 11, False, "f32", False, False),     # fp32 output and residual, Cout % 32 != 0
+    (2, 1024, 640, 3, 1, 8, 10, False, "", False, False),       # two destinations would need split < Cout: single fp32 destination here, 288 steps
+]
+
+
+@pytest.mark.parametrize("case", FOLD_CASES, ids=lambda c: "x".join(map(str, c[:7])))
+def test_conv2d_split_k_is_independent_of_chip_share_bitwise(case):
+    """Round 6: a layer that splits K gives the SAME BITS whether its slices run as separate workgroups + splitk_reduce_kernel (one launch stream:
+    mivos_conv_desc.chip_share <= 1) or one after the other inside one workgroup (conv_f16x3_pp_kernel<..., FOLD>: chip_share > 1, what the lanes of a
+    suite / the two passes of an interaction say).  Round 5's share-aware slice COUNT changed the fp32 summation order, and with it a clip's masks."""
+    n, cin, cout, k, stride, h, w, relu_out, res_kind, use_bn, out_act = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5) if use_bn else None
+    L = ConvLayer.pack(wt, b, bn, stride, k // 2).to(DEV)
+    xa = ops.to_act(nhwc(x).to(DEV))
+    ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+    r = None
+    if res_kind:
+        res = torch.randn(n, ho, wo, cout, generator=g).to(DEV)
+        r = res if res_kind == "f32" else ops.to_act(res)
+    outs = []
+    for share in (1, 2, 3):
+        with ops.chip_share(share):
+            y = ops.conv(xa, L, relu_out=relu_out, res=r, out_act=out_act)
+        outs.append((y.buf if out_act else y).clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)) and torch.equal(outs[0].view(torch.int32), outs[2].view(torch.int32))
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=k // 2)
+    if bn is not None:
+        ref = F.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0., 1e-5)
+    if res_kind:
+        ref = ref + res.cpu().permute(0, 3, 1, 2).double()
+    if relu_out:
+        ref = F.relu(ref)
+    got = ops.to_f32(ops.Act(outs[1], n, ho, wo, cout)) if out_act else outs[1]
+    assert rel_err(got.cpu().permute(0, 3, 1, 2), ref) < max(2e-6, 6e-8 * (cin * k * k) ** 0.5)
+
+
 def test_conv2d_lds_dma_dual_destination_and_batch_slices():
     """KeyValue-style split into two fp32 destinations from an Act input; Act batch slices keep their borders."""
     g = torch.Generator().manual_seed(3)

@@ -244,3 +244,47 @@ def test_gui_call_pattern_golden(golden_dir, synthetic_states):
     names = [n for n, _ in g.events]
     reset = g.events[names.index("reset")][1]
     assert not reset[2].any() and reset[3].any()
+
+
+def test_long_horizon_fixtures_are_pinned_to_the_oracle(golden_dir):
+    """tests/golden/long_s<seed>_k<K>.npz (oracle/make_golden_long.py: the UNMODIFIED reference's fp32 run and an fp64 run of config 3's full 137-step
+    session) - what a CPU suite can check in seconds: every fixture is complete and self-consistent (shapes, the admission record it carries, the
+    conditioning it was made with = the FROZEN synthetic.CLOSED_LOOP_CONDITIONING), and for one of them the FIRST propagated frame of the session,
+    recomputed here by the oracle on the same clip and weights, reproduces the stored reference masks and fp64 probabilities."""
+    import glob
+    from mivos_amd.util import synthetic
+    from mivos_amd.util.tensor_util import compute_np_iou
+    from oracle import make_golden_long as G
+    paths = sorted(glob.glob(os.path.join(golden_dir, "long_s*_k*.npz")))
+    assert len(paths) >= 3
+    for path in paths:
+        z = G.load(path)
+        cfg = json.loads(str(z["config"]))
+        K, T, sub = cfg["objects"], cfg["frames"], cfg["sub"]
+        assert cfg["conditioning"] == synthetic.CLOSED_LOOP_CONDITIONING and cfg["interactions"] == [0, T - 1] and T == 70 and cfg["top_k"] == 50
+        nh, nw = (cfg["height"] + 15) // 16 * 16, (cfg["width"] + 15) // 16 * 16
+        kept = z["frames"]
+        for n in range(2):
+            assert z[f"masks32_{n}"].shape == (T, cfg["height"], cfg["width"]) and z[f"masks32_{n}"].dtype == np.uint8 and z[f"masks64_{n}"].shape == z[f"masks32_{n}"].shape
+            assert z[f"p64_{n}"].shape == (K + 1, len(kept), -(-nh // sub), -(-nw // sub)) == z[f"d32_{n}"].shape
+            adm = z[f"admission_{n}"]
+            live = adm[~np.isnan(adm)]
+            assert len(live) == (T - 1 if n == 0 else T - 2)
+            # the stored admission IS the IoU of the two stored mask sets
+            t = int(np.nanargmin(adm))
+            iou = float(np.mean([compute_np_iou(z[f"masks32_{n}"][t] == j, z[f"masks64_{n}"][t] == j) for j in range(1, K + 1)]))
+            assert abs(iou - adm[t]) < 1e-9
+        worst = min(float(np.nanmin(z["admission_0"])), float(np.nanmin(z["admission_1"])))
+        assert abs(worst - cfg["worst_self_iou"]) < 1e-9 and cfg["admitted"] == (worst >= cfg["admission_bar"])
+    # first propagated frame of the smallest session, recomputed (fp32: masks; fp64: probabilities at the kept samples of frame 0 .. the first kept frame > 0 is 5)
+    path = min(paths, key=lambda p: json.loads(str(np.load(p)["config"]))["objects"])
+    z = G.load(path)
+    cfg = json.loads(str(z["config"]))
+    K = cfg["objects"]
+    images, gt = synthetic.synthetic_clip(cfg["frames"], cfg["height"], cfg["width"], K, seed=cfg["seed"])
+    sd = synthetic.condition_state(synthetic.make_prop_state(0), **cfg["conditioning"])
+    fsd = synthetic.make_fuse_state(0)
+    core = O.OracleCore(sd, fsd, images[:, :2], K, mem_freq=cfg["mem_freq"], top_k=cfg["top_k"])
+    masks = core.interact(gt[0], 0)
+    iou = float(np.mean([compute_np_iou(masks[1] == j, z["masks32_0"][1] == j) for j in range(1, K + 1)]))
+    assert iou >= 0.99995, iou            # (bit-identical up to the host's thread count: the fixture was made with another number of threads)
