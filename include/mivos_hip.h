@@ -111,6 +111,11 @@ typedef struct {
 } mivos_conv_desc;
 
 int mivos_conv2d_fused(const mivos_conv_desc *d, void *stream);
+/* How a precision-2 layer that splits K runs its slices (results are bit-identical in every mode: same slices, same fp32 additions in the same order):
+ * 0 = always as gridDim.y workgroups + a reduce pass; 1 (default) = folded one after the other inside one workgroup per tile when the descriptor says
+ * other streams share the chip (chip_share > 1) and the tile grid has >= 64 workgroups; 2 = always folded (tests, tuning).  Process-wide; returns the
+ * previous mode, an out-of-range argument only queries.  Environment variable MIVOS_PP_FOLD sets the initial value. */
+int mivos_conv2d_set_fold_mode(int mode);
 /* Pack OHWI fp32 weights [Cout][KH][KW][Cin] for precision 1.  out[Cout][Kpad/4][8 halves]: per 4
  * consecutive K positions the 4 fp16 "hi" parts of w*mult followed by the 4 fp16 "lo" parts
  * (w*mult - hi); Kpad = KH*KW*Cin rounded up to a multiple of 64 (zero filled).  For Cin % 32 == 0 the

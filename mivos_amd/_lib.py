@@ -70,6 +70,7 @@ PROTOTYPES = {
     "mivos_conv2d_variant": (C.c_int, [C.c_int, C.c_int]),
     "mivos_conv2d_variant_f16x3": (C.c_int, [C.c_int, C.c_int]),
     "mivos_conv2d_variant_pp": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "mivos_conv2d_set_fold_mode": (C.c_int, [C.c_int]),
     "mivos_maxpool3x3s2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_upsample2x_add": (C.c_int, [vp, i64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mivos_upsample2x_add_multi": (C.c_int, [vp, i64, vp, vp, vp, vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

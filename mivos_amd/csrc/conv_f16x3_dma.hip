@@ -394,6 +394,8 @@ __global__ void pack_weights_dma_kernel(const float *__restrict__ w, unsigned ch
   }
 }
 
+static std::atomic<int> g_fold_mode{getenv("MIVOS_PP_FOLD") ? atoi(getenv("MIVOS_PP_FOLD")) : 1};
+
 static FILE *shape_log_file() {
   static FILE *const f = getenv("MIVOS_CONV_LOG") ? fopen(getenv("MIVOS_CONV_LOG"), "a") : nullptr;
   return f;
@@ -431,12 +433,14 @@ static int launch_pp(ConvP &p, hipStream_t st) {
   if (force_slices && p.vec_epi && p.ws && (long long)force_slices * p.M * p.Cout * 4 <= p.ws_bytes && nk >= 2 * force_slices) slices = force_slices;
   p.kt_split = 0;
   if (slices > 1) { p.kt_split = cdiv(nk, slices); slices = cdiv(nk, p.kt_split); p.partial = (float *)p.ws; }
-  // The caller keeps other launch streams busy (chip_share > 1): the same K slices, folded inside one workgroup each (see FOLD above) - identical bits, no
-  // partial sums, no reduce launch.  Tiles up to 128x128 only (the accumulators of the total must fit the register file); MIVOS_PP_FOLD=0 never folds,
-  // =2 folds every split layer whatever the hint (A/B, tests).
-  static const int fold_mode = getenv("MIVOS_PP_FOLD") ? atoi(getenv("MIVOS_PP_FOLD")) : 1;
+  // The caller keeps other launch streams busy (chip_share > 1) and the split grid would be large (>= 64 tiles x slices): the same K slices, folded inside
+  // one workgroup each (see FOLD above) - identical bits, no partial sums, no reduce launch, the slots stay free for the neighbour streams.  Small grids
+  // (one-object clips: 26 tiles) split physically whatever the hint: measured same box, three one-object clips in flight 568 frames/s split vs 540 folded; two
+  // five-object clips 202.7 vs 200.7 (profiles/r06c_fold_ab.txt).  Tiles up to 128x128 only (the accumulators of the total must fit the register file).
+  // MIVOS_PP_FOLD=0 never folds, =2 folds every split layer whatever the hint or the grid (A/B, tests: mivos_conv2d_set_fold_mode).
+  const int fold_mode = g_fold_mode.load(std::memory_order_relaxed);
   if constexpr (ABL == 0 && BM * BN <= 128 * 128) {
-    if (slices > 1 && (fold_mode == 2 || (fold_mode == 1 && p.share > 1))) {
+    if (slices > 1 && (fold_mode == 2 || (fold_mode == 1 && p.share > 1 && wgs >= 64))) {
       auto kfold = conv_f16x3_pp_kernel<BM, BN, WGM, WGN, 0, true>;
       static std::atomic<uint64_t> fold_attr_mask{0};
       if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kfold), lds, fold_attr_mask, "conv_f16x3_pp (folded)")) return rc;
@@ -514,6 +518,12 @@ int launch_conv_f16x3_dma(ConvP &p, hipStream_t st) {
 using namespace mivos;
 
 extern "C" int mivos_conv2d_variant_pp(int M, int Cout, int ksteps) { return select_variant_pp(M, Cout, ksteps); }
+
+extern "C" int mivos_conv2d_set_fold_mode(int mode) {
+  const int prev = g_fold_mode.load(std::memory_order_relaxed);
+  if (mode >= 0 && mode <= 2) g_fold_mode.store(mode, std::memory_order_relaxed);
+  return prev;
+}
 
 extern "C" int mivos_pack_activation_sh32(const float *x, int64_t x_nstride, int64_t x_rstride, int64_t x_pstride, void *y, int64_t y_nstride,
                                            int64_t y_rstride, int64_t y_pstride, int N, int H, int W, int C, int relu, void *stream) {

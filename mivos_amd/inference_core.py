@@ -201,7 +201,11 @@ class InferenceCore:
     # fusion launches therefore go to a second HIP stream behind an event and run beside the next memorize / decode launches:
     # FusionNet is HBM-bound, the encoder GEMMs are matrix-core bound.  Same kernels, same arithmetic, same results.
     FUSE_ON_SIDE_STREAM = os.environ.get("MIVOS_FUSE_SIDE_STREAM", "1") != "0"
-    FUSE_BESIDE_MEMORIZE = os.environ.get("MIVOS_FUSE_BESIDE_MEMORIZE", "0") != "0"      # A/B (round 6): where the side stream's start event is recorded
+    # Where the side stream's start event is recorded: behind `aggregate` (the fusion kernels of frame t then run beside memorize(t)) or behind memorize(t)
+    # (beside frame t + 1's read and decoder).  Same kernels either way.  Measured same box (profiles/r06c_fold_ab.txt): ONE clip in flight 194.4 vs 198.0
+    # frames/s (the HBM-bound fusion kernels and the memory encoder's HBM-bound 1x1 layers get in each other's way), TWO clips in flight 223.4 vs 200.9
+    # (the other clip's launches fill the encoder's holes anyway).  "auto": beside memorize exactly when the caller says other streams share the chip.
+    FUSE_BESIDE_MEMORIZE = os.environ.get("MIVOS_FUSE_BESIDE_MEMORIZE", "auto")
 
     def _fuse_async(self, closest, idx, ti, out, key_k, q, pending):
         main = torch.cuda.current_stream()
@@ -250,7 +254,8 @@ class InferenceCore:
                                                keys_split=None if ksplit is None else ksplit[:, :st.n_read].reshape(K, st.n_read * hw, CK))
                 out = ops.aggregate(prob_k.unsqueeze(1), keep_bg=True)            # [K+1,1,nh,nw]
                 side_fuse = st.fuse and self.FUSE_ON_SIDE_STREAM and self.result_dev == self.device
-                if side_fuse and self.FUSE_BESIDE_MEMORIZE:
+                beside = side_fuse and (ops.CHIP_SHARE > 1 if self.FUSE_BESIDE_MEMORIZE == "auto" else self.FUSE_BESIDE_MEMORIZE not in ("0", 0, False))
+                if beside:
                     # enqueued BEFORE memorize: the side stream's start event then sits right behind `aggregate`, and the fusion kernels run beside
                     # this frame's memory encoder (under-filled 30 x 54 layers) instead of beside the NEXT frame's read + decoder
                     self._fuse_async(closest, idx, st.ti, out, key_k, q, pending)
@@ -259,7 +264,7 @@ class InferenceCore:
                                                 key_out=keys[:, st.slot], val_out=values[:, st.slot])
                     if ksplit is not None:
                         ops.split_keys(keys[:, st.slot], ksplit[:, st.slot])
-                if side_fuse and self.FUSE_BESIDE_MEMORIZE:
+                if beside:
                     pass
                 elif side_fuse:
                     self._fuse_async(closest, idx, st.ti, out, key_k, q, pending)

@@ -208,6 +208,8 @@ def run_resblock_acts(plan, raw, rel, res1=None, res_skip=None):
     res1 / res_skip: partial sums (fp32, batch 1, broadcast) added to conv1 / to the skip convolution - the contribution of
     input channels that are identical for every object and were convolved once (Decoder.compress, see prop_net.segment)."""
     c1, c2, ds = plan
+    # (Round 6 measured the skip convolution / the stages' projection shortcuts on a side stream beside conv1: same box, one clip in flight 201.9 vs 201.9
+    # frames/s, two clips 187 vs 223 - the extra stream's event traffic costs more than the overlap gives; profiles/r06d_branch_stream_ab.txt.  Not kept.)
     r = ops.conv(rel, c1, relu_out=True, res=res1, out_act=True, tag="resblock.mid")
     skip = raw if ds is None else ops.conv(raw, ds, res=res_skip)
     return ops.conv(r, c2, res=skip)

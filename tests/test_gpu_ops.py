@@ -267,13 +267,22 @@ def test_conv2d_split_k_is_independent_of_chip_share_bitwise(case):
     if res_kind:
         res = torch.randn(n, ho, wo, cout, generator=g).to(DEV)
         r = res if res_kind == "f32" else ops.to_act(res)
+    from mivos_amd import _lib
+    lib = _lib.load()
     outs = []
-    for share in (1, 2, 3):
-        with ops.chip_share(share):
-            y = ops.conv(xa, L, relu_out=relu_out, res=r, out_act=out_act)
-        outs.append((y.buf if out_act else y).clone())
+    old_mode = lib.mivos_conv2d_set_fold_mode(-1)
+    try:
+        # (share, fold mode): the default rule with one / two / three streams, then every split layer forced through the split + reduce route and through
+        # the folded route (small grids fold only when forced: mivos_conv2d_set_fold_mode)
+        for share, mode in ((1, 1), (2, 1), (3, 1), (2, 0), (1, 2)):
+            lib.mivos_conv2d_set_fold_mode(mode)
+            with ops.chip_share(share):
+                y = ops.conv(xa, L, relu_out=relu_out, res=r, out_act=out_act)
+            outs.append((y.buf if out_act else y).clone())
+    finally:
+        lib.mivos_conv2d_set_fold_mode(old_mode)
     torch.cuda.synchronize()
-    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)) and torch.equal(outs[0].view(torch.int32), outs[2].view(torch.int32))
+    assert all(torch.equal(outs[0].view(torch.int32), o.view(torch.int32)) for o in outs[1:])
     ref = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=k // 2)
     if bn is not None:
         ref = F.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0., 1e-5)
