@@ -102,6 +102,7 @@ class StubCore:
                 return e.value
 
 
+LANE_CLIPS = {}           # lane -> (images, gt) for lanes >= 1 of the several-clips-in-flight measurements (lane 0 and the headline use the main clip)
 CORE_FACTORY = None       # --stub-engine: callable(images, objects) -> StubCore; None = mivos_amd.inference_core.InferenceCore on the GPU
 
 
@@ -241,9 +242,9 @@ class ClockSampler:
     ~0.3 s from a thread; the tool is part of the ROCm image and readable by an ordinary user).  `summary()` is None-safe: a box without the tool
     yields {"available": false, ...} instead of numbers."""
 
-    def __init__(self, device_index=0, period=0.3):
+    def __init__(self, device_index=0, period=0.3, enabled=True):
         import threading
-        self.idx, self.period, self.samples, self.error = device_index, period, [], None
+        self.idx, self.period, self.samples, self.error, self.enabled = device_index, period, [], None, enabled
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._run, daemon=True)
 
@@ -262,12 +263,14 @@ class ClockSampler:
             self._stop.wait(self.period)
 
     def __enter__(self):
-        self._thread.start()
+        if self.enabled:                 # (rank 0 only: eight ranks need not run eight pollers)
+            self._thread.start()
         return self
 
     def __exit__(self, *exc):
         self._stop.set()
-        self._thread.join(timeout=6)
+        if self.enabled:
+            self._thread.join(timeout=6)
 
     def summary(self, t0, t1):
         """Statistics of the samples taken inside [t0, t1] (perf_counter stamps of the timed region)."""
@@ -476,12 +479,13 @@ def run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, mem_freq, 
 
         def session_loop(lane):
             while not clock.done:
-                core = make_core(prop, fuse, images, cfg["objects"], mem_freq, dev)
+                im_l, gt_l = LANE_CLIPS.get(lane, (images, gt))      # lanes > 0 work on clips of their own (other frames, other masks; same shape)
+                core = make_core(prop, fuse, im_l, cfg["objects"], mem_freq, dev)
                 clock.cores[lane] = core
                 clock.arm()
                 for i in cfg["interactions"]:
                     idx = i % T
-                    out = yield from core.interact_steps(gt[idx], idx, step_cb=clock)
+                    out = yield from core.interact_steps(gt_l[idx], idx, step_cb=clock)
                     if firsts[lane] is None:
                         firsts[lane] = out.copy()
                     if clock.done:
@@ -514,7 +518,8 @@ def run_full_session(torch, shard, cfg, images, gt, prop, fuse, dev, mem_freq, l
     do_pass loop (memorize of the interacted frame, final argmax + D2H of the masks).  lanes > 1: that many complete sessions in
     flight, one HIP stream each, advanced in turn frame by frame; steps = the frames of all of them."""
     T = images.shape[1]
-    cores = [make_core(prop, fuse, images, cfg["objects"], mem_freq, dev) for _ in range(lanes)]
+    clips = [LANE_CLIPS.get(lane, (images, gt)) if lanes > 1 else (images, gt) for lane in range(lanes)]
+    cores = [make_core(prop, fuse, clips[lane][0], cfg["objects"], mem_freq, dev) for lane in range(lanes)]
     gpu_sync(torch); shard.barrier(); gpu_sync(torch)
     t0 = time.perf_counter()
     per = []
@@ -525,14 +530,14 @@ def run_full_session(torch, shard, cfg, images, gt, prop, fuse, dev, mem_freq, l
             core.interact(gt[i % T], i % T)
             per.append(core.propagated_frames - before)
     else:
-        def session(core):
+        def session(core, gt_l):
             for i in cfg["interactions"]:
-                yield from core.interact_steps(gt[i % T], i % T)
+                yield from core.interact_steps(gt_l[i % T], i % T)
         streams = lane_streams(torch, dev, lanes)
         for st_ in streams:
             st_.wait_stream(torch.cuda.current_stream())
         from mivos_amd import ops
-        loops = [session(c) for c in cores]
+        loops = [session(c, clips[lane][1]) for lane, c in enumerate(cores)]
         live = list(range(lanes))
         with ops.chip_share(lanes):
             while live:
@@ -689,6 +694,9 @@ def main():
         images, gt = synthetic.synthetic_clip(T, cfg["height"], cfg["width"], K, seed=100 + rank)
         images, gt = images.to(dev), gt.to(dev)                # resident in HBM before the clock starts
 
+    if args.lanes > 1 and not args.stub_engine:      # the other lanes propagate OTHER clips (same shape, other seed): nothing of theirs is warm in a cache because lane 0 read it
+        for lane in range(1, args.lanes):
+            LANE_CLIPS[lane] = synthetic.synthetic_clip_device(T, cfg["height"], cfg["width"], K, seed=1000 * lane + 100 + rank, device=dev)
     if args.profile_every is None:
         args.profile_every = 21 if steps >= 400 else (7 if steps >= 40 else 3)
     # HEADLINE: ONE session (clip) in flight - the reference's workload is one interactive session at a time (and rounds 1-4 measured that).
@@ -696,7 +704,7 @@ def main():
     # measure the CUs the neighbour holds.  Several clips in flight per GPU (--lanes) is a separate, labelled field below.
     preroll, n_plain, n_fused = window_phase(cfg, T, warmup, steps)
     sustained_is_headline = args.config in (2, 3) and steps >= 5 * session        # the default `python bench.py` (8 sessions): the headline IS sustained
-    with ClockSampler(local) as smi:
+    with ClockSampler(local, enabled=rank == 0) as smi:
         clock, masks_first = run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, warmup, steps, args.profile_every, lanes=1, preroll=preroll)
     elapsed = shard.max_over_ranks(clock.t1 - clock.t0, device=dev)
     headline_clocks = smi.summary(clock.t0, clock.t1) if rank == 0 else None
@@ -736,7 +744,7 @@ def main():
             n_sess = 8 if args.config == 3 else 16
             sustained = {}
             for ln in sorted({1, args.lanes}):
-                with ClockSampler(local) as smi2:
+                with ClockSampler(local, enabled=rank == 0) as smi2:
                     cs, _ = run_sessions(torch, ops, shard, cfg, images, gt, prop, fuse, dev, args.mem_freq, session, n_sess * session, 0, lanes=ln)
                 es = shard.max_over_ranks(cs.t1 - cs.t0, device=dev)
                 rec = dict(value=round(world * n_sess * session / es, 3), unit="frames/s", ms_per_step=round(es / (n_sess * session) * 1e3, 3), steps=n_sess * session,

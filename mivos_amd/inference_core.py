@@ -125,7 +125,6 @@ class InferenceCore:
 
         self.query_buf, self.image_buf = {}, {}
         self._lookahead = set()                      # frames encoded ahead of their use (not yet consumed by a pass)
-        self._inflight = None                        # (frames, features, event) of a batch being encoded on the query side stream (QUERY_PREFETCH)
         self.interacted = set()
         self._certain_k = self._certain_v = None     # [K, n, h, w, C] rows per memory position
         self.propagated_frames = 0                   # do_pass iterations so far (the bench metric)
@@ -168,17 +167,11 @@ class InferenceCore:
         """Cached query features of frame idx.  On a miss the next not-yet-cached frames of the running pass
         (`upcoming`, in processing order) are encoded in the same batch: the features are state independent,
         so this is the reference's lazy cache (:110-120) filled a few frames ahead.
-        (Encoding the NEXT batch on the side stream while the current one is consumed was built and measured in round 3:
-        +0.8 % on the full config-3 session, -4 % on a 20-step window that starts with an empty cache; not kept.)"""
+        (Encoding the NEXT batch on a side stream while the current one is consumed was built and measured twice: round 3 +0.8 % on the full
+        config-3 session; round 6, same box, one clip in flight +1 % (201.9 vs 200.1 frames/s), two clips in flight -17 % (187 vs 225: a fifth
+        and sixth active stream on HIP's four hardware queues), on a lowest-priority HIP stream -5 % / +0 % (profiles/r06e_query_prefetch_ab.txt).
+        Not kept.)"""
         q = self.query_buf.get(idx)
-        if q is None and self._inflight is not None and idx in self._inflight[0]:
-            todo, feats, done = self._inflight            # the batch that was launched ahead on the side stream: wait for it on THIS stream
-            self._inflight = None
-            torch.cuda.current_stream().wait_event(done)
-            for t, qt in zip(todo, feats):
-                self.query_buf[t] = qt
-            self._lookahead.update(t for t in todo if t != idx)
-            q = self.query_buf[idx]
         if q is None:
             if len(self.query_buf) > self.q_buf_size:
                 self.query_buf, self._lookahead = {}, set()
@@ -192,56 +185,10 @@ class InferenceCore:
         self._lookahead.discard(idx)
         return q
 
-    # Query features are state independent: the NEXT batch of a pass can be encoded while the current one is consumed.  "0": off (the batch is encoded
-    # on the pass's stream when its first frame comes up: 8 ms every 10th frame at 480p); "1": on a side stream, launched when PREFETCH_AT frames of the
-    # current batch are left; "low": that side stream has the lowest HIP priority, so the pass's own launches win the workgroup slots.
-    QUERY_PREFETCH = os.environ.get("MIVOS_QUERY_PREFETCH", "0")
-    PREFETCH_AT = int(os.environ.get("MIVOS_QUERY_PREFETCH_AT", "6"))
-
-    def _absorb_inflight(self):
-        """Move a batch that is (or was) being encoded on the side stream into the cache (the current stream waits for it)."""
-        if self._inflight is not None:
-            todo, feats, done = self._inflight
-            self._inflight = None
-            torch.cuda.current_stream().wait_event(done)
-            for t, qt in zip(todo, feats):
-                self.query_buf.setdefault(t, qt)
-            self._lookahead.update(todo)
-
-    def _prefetch(self, upcoming):
-        """Launch the encoding of the next QUERY_BATCH not-yet-cached frames of `upcoming` on the query side stream (at most one batch in flight)."""
-        if self.QUERY_PREFETCH == "0" or self.data_dev != self.device:
-            return
-        if self._inflight is not None:
-            if any(t in self._inflight[0] for t in upcoming):
-                return
-            self._absorb_inflight()        # a batch nobody of this pass will ask for (left by an earlier pass): keep it, free the slot
-        cached_ahead = 0
-        for t in upcoming:
-            if t not in self.query_buf:
-                break
-            cached_ahead += 1
-        if cached_ahead > self.PREFETCH_AT or cached_ahead == len(upcoming):
-            return
-        todo = [t for t in upcoming if t not in self.query_buf][:self.QUERY_BATCH]
-        if len(todo) < 2 or len(self.query_buf) + len(todo) > self.q_buf_size:
-            return
-        main = torch.cuda.current_stream()
-        side = ops.side_stream(self.device, "query", low_priority=self.QUERY_PREFETCH == "low")
-        side.wait_stream(main)            # also orders the side stream behind every earlier reader of the blocks its allocator pool may hand out again
-        with torch.cuda.stream(side), ops.range_status(self._range):
-            feats = self._encode(todo)
-            done = torch.cuda.Event()
-            done.record(side)
-        self._inflight = (todo, feats, done)
-
     def drop_lookahead(self):
         """Forget query features that were encoded ahead of their frame's turn (benchmark hygiene: a timed region that
         starts here contains the encoding work of every frame it propagates).  Returns how many were dropped."""
-        n = len(self._lookahead) + (len(self._inflight[0]) if self._inflight is not None else 0)
-        if self._inflight is not None:
-            torch.cuda.current_stream().wait_event(self._inflight[2])      # its tensors die here: order their release behind the launches that write them
-            self._inflight = None
+        n = len(self._lookahead)
         for t in self._lookahead:
             self.query_buf.pop(t, None)
         self._lookahead = set()
@@ -304,8 +251,6 @@ class InferenceCore:
         for si, st in enumerate(steps):
             with ops.range_status(self._range):              # (per step: never held across the yield)
                 q = self._query(st.ti, upcoming=[s2.ti for s2 in steps[si + 1:si + self.QUERY_BATCH]])
-                if self.QUERY_PREFETCH != "0":
-                    self._prefetch([s2.ti for s2 in steps[si + 1:si + 1 + 2 * self.QUERY_BATCH]])
                 prob_k = self.prop_net.segment(keys[:, :st.n_read].reshape(K, st.n_read * hw, CK),
                                                values[:, :st.n_read].reshape(K, st.n_read * hw, CV), q,
                                                keys_split=None if ksplit is None else ksplit[:, :st.n_read].reshape(K, st.n_read * hw, CK))

@@ -94,25 +94,7 @@ def chip_share(n):
 _side_streams = {}
 
 
-def _low_priority_stream(device):
-    """A HIP stream of the LOWEST priority on `device` (torch.cuda.Stream only offers normal / high): created through the HIP runtime torch itself has
-    loaded and wrapped as a torch ExternalStream.  None when the runtime refuses (the caller then falls back to an ordinary stream)."""
-    import ctypes
-    try:
-        hip = ctypes.CDLL("libamdhip64.so")
-        least, greatest = ctypes.c_int(0), ctypes.c_int(0)
-        with torch.cuda.device(device):
-            if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0 or least.value <= 0:
-                return None
-            handle = ctypes.c_void_p()
-            if hip.hipStreamCreateWithPriority(ctypes.byref(handle), ctypes.c_uint(0), ctypes.c_int(least.value)) != 0 or not handle.value:
-                return None
-        return torch.cuda.ExternalStream(handle.value, device=device)
-    except Exception:
-        return None
-
-
-def side_stream(device, purpose, low_priority=False):
+def side_stream(device, purpose):
     """The side HIP stream `purpose` ("fuse", "pass", ...) of the CURRENT stream on `device`, created once per process and reused by every core /
     generator that works under that stream.  A fresh torch.cuda.Stream per InferenceCore (rounds 3-5) meant a fresh allocator pool and fresh
     per-stream workspaces / scratch for every clip: ~30 ms of hipMalloc with the GPU idle at the first fused frame of every session (rocprofv3
@@ -121,8 +103,7 @@ def side_stream(device, purpose, low_priority=False):
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream, purpose)
     st = _side_streams.get(key)
     if st is None:
-        st = (_low_priority_stream(device) if low_priority else None) or torch.cuda.Stream(device=device)
-        _side_streams[key] = st
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
     return st
 
 
