@@ -39,6 +39,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 # fp16 MFMA dense peak (2.5 PFLOP/s) / 3 MFMA products per algorithmic multiply-add of the error-compensated
 # f16x3 convolution = the roofline of that kernel in ALGORITHMIC (fp32-equivalent) FLOP/s
 F16X3_PEAK_TFLOPS = 2500.0 / 3
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s (6.3 achievable)
 VARIANT_NAMES = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<64,64,2,2>",
                  2: "conv_igemm_kernel<128,32,4,1>", 3: "conv_igemm_kernel<128,64,2,2>", 4: "conv_cout1_kernel",
                  10: "conv_f16x3_kernel<128,128,2,2>", 11: "conv_f16x3_kernel<64,64,2,2>", 12: "conv_f16x3_kernel<128,32,4,1>",
@@ -329,17 +330,25 @@ def kernel_rooflines(samples, overhead=0.0, config=3, select_kernel=None):
     """Aggregate the HIP-event samples per kernel instantiation.  Returns (dominant conv kernel's roofline record, the
     memory-read affinity record, per-kernel table)."""
     agg = {}
+    bound = {}            # per conv instantiation: launches split by the roofline that bounds their SHAPE (arithmetic intensity against the ridge point)
+    ridge = F16X3_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
     for variant, flops, e0, e1, shape in samples:
         a = agg.setdefault(variant, [0.0, 0.0, 0, 0.0])
+        secs = max(e0.elapsed_time(e1) * 1e-3 - overhead, 1e-7)
         a[0] += flops
-        a[1] += max(e0.elapsed_time(e1) * 1e-3 - overhead, 1e-7)
+        a[1] += secs
         a[2] += 1
         if variant == 30:
             a[3] += shape[-1]
         elif variant < 90:
             m, cin, cout, k, stride, has_res = shape
             # one read of the input, the weights and the residual, one write of the output (4 B per element)
-            a[3] += 4.0 * m * stride * stride * cin + 4.0 * cout * k * k * cin + 4.0 * m * cout * (2 if has_res else 1)
+            nbytes = 4.0 * m * stride * stride * cin + 4.0 * cout * k * k * cin + 4.0 * m * cout * (2 if has_res else 1)
+            a[3] += nbytes
+            if variant >= 10:
+                b = bound.setdefault(variant, {"mfma": [0.0, 0.0, 0.0, 0, 0.0], "hbm": [0.0, 0.0, 0.0, 0, 0.0]})["hbm" if flops / nbytes < ridge else "mfma"]
+                b[0] += flops; b[1] += nbytes; b[2] += secs; b[3] += 1
+                b[4] += max(flops / (F16X3_PEAK_TFLOPS * 1e12), nbytes / (HBM_PEAK_GBS * 1e9))      # the time the roofline allows this launch
         else:
             a[3] += shape[-1]
     if not agg:
@@ -359,6 +368,20 @@ def kernel_rooflines(samples, overhead=0.0, config=3, select_kernel=None):
                                if v >= 10 else "fp32 MFMA dense peak"),
                     avg_launch_us=round(secs / n * 1e6, 2), algorithmic_gflop_per_launch=round(flops / n / 1e9, 3),
                     algorithmic_bytes_per_launch=int(abytes / n))
+        if v in bound:
+            # The instantiation serves ~30 layer shapes, some MFMA-bound, some HBM-bound at 4 bytes per activation (the 1x1 expansions with a residual:
+            # 129 600 x 64 -> 256 moves 300 MB for 4 GFLOP).  `frac` above prices every launch against the MFMA peak; this block prices each launch against
+            # the roofline that bounds its SHAPE (arithmetic intensity vs the ridge at peak_flops / peak_bytes) and sums the times the roofline allows.
+            grp, allowed = {}, 0.0
+            for name, (f_, b_, t_, n_, allow_) in bound[v].items():
+                allowed += allow_
+                if n_:
+                    grp[name] = (dict(launches=n_, time_share=round(t_ / secs, 3), achieved=round(f_ / t_ / 1e12, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(f_ / t_ / 1e12 / peak, 4))
+                                 if name == "mfma" else
+                                 dict(launches=n_, time_share=round(t_ / secs, 3), achieved=round(b_ / t_ / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(b_ / t_ / 1e9 / HBM_PEAK_GBS, 4),
+                                      note="algorithmic bytes: input, weights, residual and output once, 4 B per element"))
+            roof["by_bounding_roofline"] = dict(ridge_flop_per_byte=round(ridge, 1), mfma_bound_shapes=grp.get("mfma"), hbm_bound_shapes=grp.get("hbm"),
+                                                roofline_time_over_measured_time=round(allowed / secs, 4))
     aff = None
     if 90 in agg:
         flops, secs, n, abytes = agg[90]
@@ -694,7 +717,7 @@ def main():
         images, gt = synthetic.synthetic_clip(T, cfg["height"], cfg["width"], K, seed=100 + rank)
         images, gt = images.to(dev), gt.to(dev)                # resident in HBM before the clock starts
 
-    if args.lanes > 1 and not args.stub_engine:      # the other lanes propagate OTHER clips (same shape, other seed): nothing of theirs is warm in a cache because lane 0 read it
+    if args.lanes > 1 and not args.stub_engine and not os.environ.get("MIVOS_BENCH_SAME_CLIP"):      # the other lanes propagate OTHER clips (same shape, other seed): nothing of theirs is warm in a cache because lane 0 read it
         for lane in range(1, args.lanes):
             LANE_CLIPS[lane] = synthetic.synthetic_clip_device(T, cfg["height"], cfg["width"], K, seed=1000 * lane + 100 + rank, device=dev)
     if args.profile_every is None:

@@ -72,9 +72,24 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
 }
 
+// scale / bias of an epilogue, two ways.  FUSED: one fma (what the compiler made of `acc * scale + bias` in the in-kernel epilogues of rounds 1-5; now explicit).
+// Not fused: multiply, round, add, round - what splitk_reduce_kernel has always done (its multiply and its add sat in different basic blocks) and what the
+// reference's batch_norm does.  A layer's bits must not depend on HOW its K slices ran (split + reduce pass, or folded inside one workgroup: conv_f16x3_pp_kernel
+// <..., FOLD>), so the folded kernel's epilogue uses the reduce pass's arithmetic; every other launch keeps the arithmetic it had (the golden vectors of the
+// small networks, whose layers all split, are sensitive to it at the 5e-5 level: profiles/r06g_epilogue_rounding.txt).
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+#pragma clang fp contract(off)
+  const float t = a * b;
+  return t + c;
+}
+template <bool FUSED>
+__device__ __forceinline__ float scale_bias(float a, float sc, float bi) {
+  return FUSED ? __builtin_fmaf(a, sc, bi) : mul_then_add(a, sc, bi);
+}
+
 // ---- epilogues shared by the implicit-GEMM kernels ----------------------------------------------------
 // acc tile layout (32x32 MFMA C/D): lane (n = lane&31, h = lane>>5), register r -> pixel row mfma32_row(r, lane).
-template <int MT, int NT>
+template <int MT, int NT, bool FUSED = true>
 __device__ __forceinline__ void epilogue_scalar(const f32x16 (&acc)[MT][NT], const ConvP &p, int m_base, int n_base, int lane) {
   float amax = 0.f;
 #pragma unroll
@@ -96,7 +111,7 @@ __device__ __forceinline__ void epilogue_scalar(const f32x16 (&acc)[MT][NT], con
         if (m >= p.M) continue;
         const int img = m / p.HoWo, pix = m - img * p.HoWo;
         const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
-        float v = __builtin_fmaf(acc[i][j][r], sc, bi);      // (explicit fma in every epilogue and in splitk_finish4: one rounding, the same bits on every path)
+        float v = scale_bias<FUSED>(acc[i][j][r], sc, bi);
         if (p.res) v += p.res[(long long)img * p.r_ns + (long long)oh * p.r_rs + (long long)ow * p.r_ps + n];
         if (p.relu_out) v = fmaxf(v, 0.f);
         amax = fmaxf(amax, fabsf(v));
@@ -112,7 +127,7 @@ __device__ __forceinline__ void epilogue_scalar(const f32x16 (&acc)[MT][NT], con
 // accesses, 8 lanes per 128-B line (the memory-bound 1x1 expansion convs were store-issue bound with one
 // dword per lane: 1.5 TB/s).  Needs Cout, split and all strides % 4 == 0 (p.vec_epi, checked on the host).
 constexpr int EPI_PITCH = 36;
-template <int MT, int NT, int IB = (MT > 2 ? 1 : MT)>   // IB: row tiles per residual-prefetch block (bounds the live registers)
+template <int MT, int NT, int IB = (MT > 2 ? 1 : MT), bool FUSED = true>   // IB: row tiles per residual-prefetch block (bounds the live registers)
 __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float *scratch, const ConvP &p, int m_base,
                                              int n_base, int lane) {
   constexpr bool PREFETCH = MT <= 2;       // 256x256 tiles (128 accumulator VGPRs) have no registers to spare for it
@@ -161,7 +176,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float 
         for (int ps = 0; ps < 4; ++ps) {
           f32x4 v = *reinterpret_cast<const f32x4 *>(scratch + (ps * 8 + prow0) * EPI_PITCH + c4);
           if (ok[ii][ps]) {
-            v.x = __builtin_fmaf(v.x, sc.x, bi.x); v.y = __builtin_fmaf(v.y, sc.y, bi.y); v.z = __builtin_fmaf(v.z, sc.z, bi.z); v.w = __builtin_fmaf(v.w, sc.w, bi.w);
+            v.x = scale_bias<FUSED>(v.x, sc.x, bi.x); v.y = scale_bias<FUSED>(v.y, sc.y, bi.y); v.z = scale_bias<FUSED>(v.z, sc.z, bi.z); v.w = scale_bias<FUSED>(v.w, sc.w, bi.w);
             if (!PREFETCH && p.res) {
               const int m = m_base + (i0 + ii) * 32 + ps * 8 + prow0;
               const int img = m / p.HoWo, pix = m - img * p.HoWo;
@@ -186,7 +201,7 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MT][NT], float 
 // and lo parts go out as one 16-byte store each (4 lanes cover the 64 B hi + 64 B lo halves of a 128-byte line) and an
 // SH32 residual comes in as two 16-byte loads.
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-template <int MT, int NT, int IB = (MT > 2 ? 1 : MT)>
+template <int MT, int NT, int IB = (MT > 2 ? 1 : MT), bool FUSED = true>
 __device__ __forceinline__ void epilogue_sh32(const f32x16 (&acc)[MT][NT], float *scratch, const ConvP &p, int m_base, int n_base, int lane) {
   constexpr bool PREFETCH = MT <= 2;
   const int prow0 = lane >> 2, c8 = (lane & 3) * 8;
@@ -248,7 +263,7 @@ __device__ __forceinline__ void epilogue_sh32(const f32x16 (&acc)[MT][NT], float
             half8_t hi, lo;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-              float t = __builtin_fmaf(v[q], sc[q], bi[q]);
+              float t = scale_bias<FUSED>(v[q], sc[q], bi[q]);
               t += rr[ii][ps][q];
               t = p.relu_out ? fmaxf(t, 0.f) : t;
               amax = fmaxf(amax, fabsf(t));
@@ -278,9 +293,9 @@ __device__ __forceinline__ void splitk_finish4(const ConvP &p, int n_slices, int
   }
   const int img = m / p.HoWo, pix = m - img * p.HoWo;
   const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
-  // the SAME arithmetic, operation for operation, as the in-kernel epilogues (epilogue_vec / epilogue_sh32): fma(sum, scale | 1, bias | 0) + (residual | 0),
-  // so that a layer gives the same bits whether its K slices ran as separate workgroups + this pass or one after the other inside one workgroup
-  // (conv_f16x3_pp_kernel<..., FOLD>: what a launch does when other streams share the chip)
+  // the SAME arithmetic, operation for operation, as the epilogues of the folded kernel (epilogue_* <..., FUSED = false>): sum * (scale | 1), rounded, + (bias | 0),
+  // rounded, + (residual | 0), so that a layer gives the same bits whether its K slices ran as separate workgroups + this pass or one after the other inside
+  // one workgroup (conv_f16x3_pp_kernel<..., FOLD>: what a launch does when other streams share the chip)
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f}, rr = {0.f, 0.f, 0.f, 0.f};
   if (p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + n);
   if (p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + n);
@@ -288,7 +303,7 @@ __device__ __forceinline__ void splitk_finish4(const ConvP &p, int n_slices, int
     const long long ro = (long long)img * p.r_ns + (long long)oh * p.r_rs + (long long)ow * p.r_ps;
     rr = p.r_fmt ? load_sh32x4(p.res, ro, n) : *reinterpret_cast<const f32x4 *>(p.res + ro + n);
   }
-  v.x = __builtin_fmaf(v.x, sc.x, bi.x); v.y = __builtin_fmaf(v.y, sc.y, bi.y); v.z = __builtin_fmaf(v.z, sc.z, bi.z); v.w = __builtin_fmaf(v.w, sc.w, bi.w);
+  v.x = mul_then_add(v.x, sc.x, bi.x); v.y = mul_then_add(v.y, sc.y, bi.y); v.z = mul_then_add(v.z, sc.z, bi.z); v.w = mul_then_add(v.w, sc.w, bi.w);
   v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
   if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
   range_flag(p, range_max(0.f, v));

@@ -312,9 +312,10 @@ __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_
   constexpr int EIB = (3 * BM + 2 * BN) * ROWB <= 80 * 1024 ? 1 : (MT > 2 ? 1 : MT);
   if constexpr (FOLD) fold();            // the last (possibly shorter) slice; a no-op sum of zeros when the step count divides evenly
   const f32x16 (&fin)[MT][NT] = FOLD ? tot : acc;
-  if (p.y_fmt && p.split == p.Cout) epilogue_sh32<MT, NT, EIB>(fin, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
-  else if (p.vec_epi) epilogue_vec<MT, NT, EIB>(fin, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
-  else epilogue_scalar<MT, NT>(fin, p, m0 + wm * TM, n0 + wn * TN, lane);
+  // (the folded kernel finishes with the reduce pass's arithmetic - multiply, round, add - every other launch with the fused one it always had: conv_common.h)
+  if (p.y_fmt && p.split == p.Cout) epilogue_sh32<MT, NT, EIB, !FOLD>(fin, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
+  else if (p.vec_epi) epilogue_vec<MT, NT, EIB, !FOLD>(fin, reinterpret_cast<float *>(smem) + wave * 32 * EPI_PITCH, p, m0 + wm * TM, n0 + wn * TN, lane);
+  else epilogue_scalar<MT, NT, !FOLD>(fin, p, m0 + wm * TM, n0 + wn * TN, lane);
   if (ABL == 8 && blockIdx.x == 0 && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     reinterpret_cast<long long *>(p.ws)[2] = __builtin_readcyclecounter() - t_start;
