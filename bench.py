@@ -184,7 +184,7 @@ def pmc_traffic(config, kernel_name):
         except Exception:
             continue
         for name, rec in table.items():
-            if name != "_meta" and re.sub(r"[ ,]", "", name.replace("mivos::", "")) == key:
+            if name != "_meta" and re.sub(r"[ ,]", "", name.replace("mivos::", "").replace(", false>", ">")) == key:     # (", false": the FOLD flag of round 6's instantiations)
                 if _fresh(table, path) is not None:
                     return _fresh(table, path)
                 out = dict(bytes_per_launch=int(rec["read_bytes_per_launch"] + rec["write_bytes_per_launch"]),
@@ -211,7 +211,7 @@ def pmc_mfma_util(config, kernel_name):
         except Exception:
             continue
         for name, rec in table.items():
-            base = re.sub(r"^void ", "", name.replace("mivos::", "")).split("(")[0]
+            base = re.sub(r"^void ", "", name.replace("mivos::", "")).split("(")[0].replace(", false>", ">")
             if name != "_meta" and re.sub(r"[ ,]", "", base) == key:
                 if _fresh(table, path) is not None:
                     return _fresh(table, path)
