@@ -652,6 +652,12 @@ def main():
         raise SystemExit(self_spawn(sys.argv[1:], args.gpus))
     if args.lanes is None:
         args.lanes = DEFAULT_LANES.get(args.config, 1)
+    # The other BASELINE configurations, each in a process of its own, BEFORE this process creates its GPU context: a second process that holds hardware queues
+    # (even idle) costs a child with seven streams a third of its rate (config 2, three clips in flight: 350 vs 583 frames/s, same box, profiles/r06z_*).
+    extras = None
+    if (args.other_configs and args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.config == 3 and not args.stub_engine
+            and (args.cpu_frames is None or args.cpu_frames > 1)):      # (the full line only: tuning runs pass --cpu-frames 0)
+        extras = other_configs()
 
     import torch
     torch.set_grad_enabled(False)
@@ -902,10 +908,8 @@ def main():
         out["cpu_baseline"], out["parity"] = cpu_baseline(torch, cfg, images, gt, args.mem_freq, prop, fuse, dev, cpu_frames, args.cpu_fp64)
     else:
         out["cpu_baseline"] = None
-    if args.other_configs and world == 1 and args.config == 3 and cpu_frames > 1:      # (the full line only: tuning runs pass --cpu-frames 0)
-        del images, gt, clock, samples
-        torch.cuda.empty_cache()
-        out["other_configs"] = other_configs()
+    if extras is not None:
+        out["other_configs"] = extras
     print(json.dumps(out))
 
 
@@ -913,7 +917,8 @@ def other_configs():
     """The other BASELINE configurations on the SAME box, each as a short run of this script in a fresh process (clean allocator, nothing shared
     with the headline measurement), summarised: config 2 (one session + whole sessions), config 4 (the first 48 clips of the suite, 3 clips in
     flight), config 5 (the full 1000-frame 1080p clip, bank growing to 200 frames).  Only in the default single-GPU config-3 run (--other-configs /
-    MIVOS_BENCH_EXTRAS=0 to skip); a run that fails or exceeds its time limit is recorded as an error string - it must never cost the line."""
+    MIVOS_BENCH_EXTRAS=0 to skip), before the calling process touches the GPU; a run that fails or exceeds its time limit is recorded as an error string -
+    it must never cost the line."""
     runs = {"config2": ["--config", "2", "--cpu-frames", "0"],        # default window: 8 sessions after one untimed session
             "config4_48clips": ["--config", "4", "--clips", "48"],
             "config5": ["--config", "5", "--cpu-frames", "0"]}
