@@ -923,6 +923,13 @@ def other_configs():
             "config4_48clips": ["--config", "4", "--clips", "48"],
             "config5": ["--config", "5", "--cpu-frames", "0"]}
     res = {}
+    # A throw-away child first: the FIRST process that drives several streams on a fresh box reads low in everything that allocates on them (same box, same command,
+    # first vs fifth process: three clips in flight 348 vs 580 frames/s, one fresh session 234 vs 421; scripts/gpu/r7w.sh) - that is the box warming up, not the engine.
+    try:
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "2", "--steps", "138", "--warmup", "69", "--cpu-frames", "0", "--no-sustained"],
+                       capture_output=True, text=True, timeout=300)
+    except Exception:
+        pass
     for name, extra in runs.items():
         t0 = time.perf_counter()
         try:
