@@ -100,10 +100,11 @@ typedef struct {
   int32_t dilation;    /* spacing of the kernel taps (0 or 1: dense).  DeepLab's atrous convolutions (model/s2m/_deeplab.py:
                           110-118, s2m_resnet.py:17-20) use 2 / 6 / 12 / 18 with pad == dilation; precision 0 / 1 only.       */
   int32_t chip_share;  /* how many independent launch streams the caller keeps busy on this GPU (0 or 1: this launch has the
-                          chip to itself).  A hint that must NEVER change results: since round 6 the convolutions ignore it (the
-                          split-K slice count = the fp32 summation order is a function of the layer shape alone; round 5's
-                          share-dependent rule made a clip's masks depend on the number of clips in flight).  Kept in the
-                          descriptor for ABI stability and for geometry decisions that leave the arithmetic untouched.          */
+                          chip to itself).  A hint that must NEVER change results: the split-K slice count (= the fp32 summation
+                          order) is a function of the layer shape alone since round 6 (round 5's share-dependent rule made a
+                          clip's masks depend on the number of clips in flight); with chip_share > 1 a precision-2 layer that
+                          splits K only runs its slices folded inside one workgroup per tile instead of as separate workgroups
+                          + a reduce pass - the same additions in the same order, bit-identical (mivos_conv2d_set_fold_mode).   */
   uint32_t *status;    /* optional device word (4-byte aligned, zeroed by the caller; NULL: off).  Precision 1 / 2 only: the
                           epilogue ORs bit 0 into it when an output value leaves the fp16 range (|y| > 65504) - such a value
                           becomes inf in the hi half of the next layer's operand split, and the ReLUs / clamps downstream would

@@ -18,7 +18,8 @@ struct ConvP {
   int y_fmt, r_fmt;                    // 0: fp32, 1: SH32 (fp16 hi | lo lines per 32 channels, conv_f16x3_dma.hip)
   int dil;                             // tap spacing (atrous convolution), >= 1
   int share;                           // launch streams the caller keeps busy on this GPU (>= 1): a hint for launch geometry that must not change results
-                                       // (round 6: the LDS-DMA kernels' split-K slicing, i.e. the fp32 summation order, no longer looks at it)
+                                       // (round 6: the LDS-DMA kernels' split-K slice COUNT, i.e. the fp32 summation order, no longer looks at it; it only
+                                       // chooses whether the slices run folded inside one workgroup - bit-identical)
   unsigned *status;                    // optional device word: bit 0 is set when an output of an f16x3 launch leaves the fp16 range (|y| > 65504)
 };
 

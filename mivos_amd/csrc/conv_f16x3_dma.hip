@@ -52,7 +52,8 @@ constexpr unsigned OOB_OFFSET = 0x80000000u;   // + any step offset stays >= num
 // p.kt_split steps the accumulator chain is closed (tot += acc, in ascending slice order; acc restarts from zero) and the epilogue works on the total.
 // Same chains, same order of the same fp32 additions as the split launch + reduce pass => the same bits (tests/test_gpu_ops.py); what a launch does when the
 // caller says other streams share the chip (mivos_conv_desc.chip_share > 1): no partial-sum round trip, no reduce launch, no workgroups in slots a
-// neighbour stream would fill.  Costs MT*NT*16 more VGPRs (128x128 tile: 115 -> ~150, one workgroup per CU - the grids that split leave 3/4 of the CUs free anyway).
+// neighbour stream would fill.  The second accumulator set costs MT*NT*16 registers, which the 128x128 / 128x64 / 64x128 tiles absorb (114 VGPRs, still four waves per SIMD);
+// the 128x256 tile (242 VGPRs) cannot, and is not instantiated folded - its launches split physically whatever the hint (same bits).
 template <int BM, int BN, int WGM, int WGN, int ABL = 0, bool FOLD = false>   // ABL: profiling ablations (1: no DMA, 2: no DMA wait, 3: no fragment reads); 9: experimental merged-half-step schedule
 __global__ __launch_bounds__(512) void conv_f16x3_pp_kernel(ConvP p, unsigned x_bytes, unsigned w_bytes) {
   static_assert(WGM * WGN == 8, "8 waves per workgroup");

@@ -292,7 +292,7 @@ class InferenceCore:
     # by frame, on two HIP streams.  Same kernels, same inputs, bit-identical results (round 6: the split-K slicing of the convolutions no
     # longer depends on how many streams share the chip); MIVOS_CONCURRENT_PASSES=0 runs them one after the other.
     CONCURRENT_PASSES = os.environ.get("MIVOS_CONCURRENT_PASSES", "1") != "0"
-    PASS_CHIP_SHARE = 2     # what the convolutions are told while the two passes are in flight (mivos_conv_desc.chip_share: launch geometry)
+    PASS_CHIP_SHARE = 2     # what the kernels are told while the two passes are in flight (ops.chip_share: launch geometry only, results do not depend on it)
 
     def _run_passes(self, rows, key_v, idx, step_cb=None):
         nc = self._certain_k.shape[1]
@@ -438,6 +438,8 @@ class InferenceCore:
             ops.check_activation_range(self._range)  # (this core's own word: the passes' streams were joined into the current one)
         return out
 
+    PINNED_RESULT_BYTES = 256 << 20
+
     @staticmethod
     def _to_host_u8(view):
         """uint8 device view [T, h, w] -> a numpy array of its own (the interaction's result, 29 MB for 70 frames of 480p): cropped into a dense
@@ -445,6 +447,8 @@ class InferenceCore:
         one stream synchronisation.  The pageable `.cpu().numpy().astype(uint8)` of rounds 1-5 cost two more host-side passes over the array
         (~5 ms per interaction with the GPU idle)."""
         dense = view.contiguous()
+        if dense.numel() > InferenceCore.PINNED_RESULT_BYTES:      # very long clips (config 5: 2 GB of masks): not worth page-locking that much host memory
+            return dense.cpu().numpy()
         host = torch.empty(dense.shape, dtype=torch.uint8, pin_memory=True)
         host.copy_(dense, non_blocking=True)
         torch.cuda.current_stream(dense.device).synchronize()

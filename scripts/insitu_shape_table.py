@@ -57,9 +57,10 @@ def table(trace_dir, log_path, skip_frames_before=0.0):
                 continue
             _, bm, bn, M, cin, cout, k, stride, res, slices, wgs, share, yfmt = log[li]
             li += 1
-            if int(wgs) * 512 != r["gx"] or int(slices) != r["gy"]:
+            folded = int(slices) < 0                 # (a negative slice count: the slices ran folded inside one workgroup per tile - gridDim.y == 1, no reduce launch)
+            if int(wgs) * 512 != r["gx"] or (1 if folded else int(slices)) != r["gy"]:
                 mismatches += 1
-            key = (f"{bm}x{bn}", int(M), int(cin), int(cout), int(k), int(stride), bool(int(res)), int(slices))
+            key = (f"{bm}x{bn}" + ("f" if folded else ""), int(M), int(cin), int(cout), int(k), int(stride), bool(int(res)), abs(int(slices)))
             s = shapes[key]
             s["n"] += 1
             s["us"] += (r["t1"] - r["t0"]) * 1e-3
@@ -67,7 +68,7 @@ def table(trace_dir, log_path, skip_frames_before=0.0):
             if prev_end is not None:
                 s["gap_us"] += max(0.0, (r["t0"] - prev_end) * 1e-3)
                 s["gaps"] += 1
-            pending_reduce = key if int(slices) > 1 else None
+            pending_reduce = key if int(slices) > 1 else None      # (folded launches have no reduce pass)
         elif "splitk_reduce_kernel" in r["name"] and pending_reduce is not None:
             s = shapes[pending_reduce]
             s["reduce_us"] += (r["t1"] - r["t0"]) * 1e-3
