@@ -35,4 +35,12 @@ MIVOS_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 20 --warmup
 python -c "
 import json; d=json.loads(open('gpurun_out/r7y_bench_2ranks_one_gpu_gloo_plumbing.json').read().strip().splitlines()[-1])
 print('2 ranks on one GPU (gloo plumbing):', d['value'], d['n_gpus'], d.get('dist_backend'), d.get('gloo_ranks'), d['per_rank'], 'sustained', d['sustained']['value'])" || tail -5 gpurun_out/r7y_2ranks.err
+timeout 900 python bench.py --config 4 > gpurun_out/r7y_bench_config4_474clips.json 2> gpurun_out/r7y_config4.err
+python -c "
+import json; d=json.loads(open('gpurun_out/r7y_bench_config4_474clips.json').read().strip().splitlines()[-1])
+print('config 4, 474 clips:', d['value'], d['steps'], d['wall_seconds'], d['config']['clips_in_flight_per_gpu'], d['config']['suite_checksum'])" || tail -3 gpurun_out/r7y_config4.err
+timeout 900 python bench.py --no-other-configs > gpurun_out/r7y_bench_config3_default_flags.json 2> gpurun_out/r7y_default.err
+python -c "
+import json; d=json.loads(open('gpurun_out/r7y_bench_config3_default_flags.json').read().strip().splitlines()[-1])
+print('config 3, default flags (8 sessions):', d['value'], d['ms_per_step'], d['clocks'], 'several', d['several_clips_in_flight']['value'], 'roof', d['roofline']['frac'], d['roofline']['timed_region']['frac'], d['sustained'].get('roofline_timed_region'))" || tail -3 gpurun_out/r7y_default.err
 echo "total $(( $(date +%s) - t0 )) s"
