@@ -294,6 +294,35 @@ def test_conv2d_split_k_is_independent_of_chip_share_bitwise(case):
     assert rel_err(got.cpu().permute(0, 3, 1, 2), ref) < max(2e-6, 6e-8 * (cin * k * k) ** 0.5)
 
 
+def test_conv2d_split_k_dual_destination_is_independent_of_chip_share_bitwise():
+    """KeyValue of a one-object clip (1024 -> 128 + 512 at 30 x 54: 65 tiles, 288 K steps -> 7 slices) writes TWO fp32 destinations from one GEMM; with other streams
+    on the chip its slices run folded (>= 64 tiles).  Same bits on both destinations for every (share, fold mode)."""
+    from mivos_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 30, 54, 1024, generator=g).to(DEV)
+    wt, b = torch.randn(640, 1024, 3, 3, generator=g) * 0.01, torch.randn(640, generator=g) * 0.1
+    L = ConvLayer.pack(wt, b, None, 1, 1)
+    L.split = 128
+    L = L.to(DEV)
+    xa = ops.to_act(x)
+    outs = []
+    old_mode = lib.mivos_conv2d_set_fold_mode(-1)
+    try:
+        for share, mode in ((1, 1), (2, 1), (2, 0), (1, 2)):
+            lib.mivos_conv2d_set_fold_mode(mode)
+            with ops.chip_share(share):
+                y1, y2 = ops.conv(xa, L)
+            outs.append((y1.clone(), y2.clone()))
+    finally:
+        lib.mivos_conv2d_set_fold_mode(old_mode)
+    torch.cuda.synchronize()
+    for y1, y2 in outs[1:]:
+        assert torch.equal(outs[0][0].view(torch.int32), y1.view(torch.int32)) and torch.equal(outs[0][1].view(torch.int32), y2.view(torch.int32))
+    ref = F.conv2d(x.cpu().permute(0, 3, 1, 2).double(), wt.double(), b.double(), padding=1)
+    assert rel_err(torch.cat(outs[1], -1).cpu().permute(0, 3, 1, 2), ref) < 6e-8 * (1024 * 9) ** 0.5
+
+
 def test_conv2d_lds_dma_dual_destination_and_batch_slices():
     """KeyValue-style split into two fp32 destinations from an Act input; Act batch slices keep their borders."""
     g = torch.Generator().manual_seed(3)
